@@ -1,0 +1,540 @@
+// crag_api.hip — host side of the C ABI declared in include/crag_dense.h.
+// Owns the device corpus (tile32 layout, see crag_search.hip), the workspaces and the launch
+// sequence prep_queries -> scan -> merge_partials.  No exceptions cross the ABI.
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/crag_dense.h"
+#include "crag_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(CRAG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+struct DevBuf {  // grow-only device scratch
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return CRAG_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(CRAG_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        bytes = want;
+        return CRAG_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct EvTriple {
+    hipEvent_t e0, e1, e2;
+};
+
+}  // namespace
+
+struct crag_index {
+    int device = 0;
+    int dim = 0;
+    int64_t capacity = 0;   // rows requested
+    int64_t cap_rows = 0;   // padded to a multiple of 32
+    int64_t size = 0;
+    int n_cu = 0;
+    float *corpus = nullptr;
+    float *inv_norm = nullptr;
+    int64_t *ids = nullptr;
+    DevBuf qtiles, partial, stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
+    std::mutex mu;
+    bool profiling = false;
+    std::vector<EvTriple> ev_pool;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int scan_groups(const crag_index *ix) {
+    // one workgroup per CU; never more workgroups than 8-row groups
+    int64_t n8 = (ix->size + 7) / 8;
+    int64_t g = ix->n_cu;
+    if (g > n8) g = n8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int search_device(crag_index *ix, const float *d_queries, int nq, int k, const uint8_t *d_mask,
+                  int64_t mask_stride, int64_t *d_out_ids, float *d_out_scores, int32_t *d_out_counts,
+                  hipStream_t st) {
+    if (nq <= 0) return CRAG_OK;
+    const int q_blocks = (nq + 31) / 32;
+    const int G = scan_groups(ix);
+    int rc;
+    if ((rc = ix->qtiles.ensure((size_t)q_blocks * crag::TILE_FLOATS * sizeof(float)))) return rc;
+    if ((rc = ix->partial.ensure((size_t)q_blocks * G * 32 * (size_t)k * sizeof(uint2)))) return rc;
+
+    // per-workgroup corpus window must stay below the buffer-descriptor / OOB-marker limit
+    const int64_t rows_per_g = (ix->size + G - 1) / G + 64;
+    if (rows_per_g * (int64_t)(crag::DIM * 4) >= (int64_t)0x7ff00000)
+        return fail(CRAG_EINVAL, "index too large for one device scan window (%lld rows)",
+                    (long long)ix->size);
+
+    HIP_TRY(crag::launch_prep_queries(d_queries, nq, ix->dim, (float *)ix->qtiles.p, st));
+
+    crag::ScanParams sp;
+    sp.corpus = ix->corpus;
+    sp.inv_norm = ix->inv_norm;
+    sp.qtiles = (const float *)ix->qtiles.p;
+    sp.mask = (const uint32_t *)d_mask;
+    sp.mask_stride_w = mask_stride / 4;
+    sp.partial = (uint2 *)ix->partial.p;
+    sp.n_rows = ix->size;
+    sp.cap_rows = ix->cap_rows;
+    sp.nq = nq;
+    sp.k = k;
+    sp.G = G;
+
+    EvTriple *ev = nullptr;
+    if (ix->profiling) {
+        if (ix->ev_used == ix->ev_pool.size()) {
+            EvTriple t;
+            HIP_TRY(hipEventCreate(&t.e0));
+            HIP_TRY(hipEventCreate(&t.e1));
+            HIP_TRY(hipEventCreate(&t.e2));
+            ix->ev_pool.push_back(t);
+        }
+        ev = &ix->ev_pool[ix->ev_used++];
+        HIP_TRY(hipEventRecord(ev->e0, st));
+    }
+    HIP_TRY(crag::launch_scan(sp, q_blocks, st));
+    if (ev) HIP_TRY(hipEventRecord(ev->e1, st));
+
+    crag::MergeParams mp;
+    mp.partial = (const uint2 *)ix->partial.p;
+    mp.ids = ix->ids;
+    mp.id_base = 0;
+    mp.out_ids = d_out_ids;
+    mp.out_scores = d_out_scores;
+    mp.out_counts = d_out_counts;
+    mp.k = k;
+    mp.G = G;
+    HIP_TRY(crag::launch_merge_partials(mp, nq, st));
+    if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
+    return CRAG_OK;
+}
+
+int check_search_args(const crag_index *ix, const void *queries, int nq, int k, const void *mask,
+                      int64_t mask_stride, const void *out_ids, const void *out_scores,
+                      const void *out_counts) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    if (nq < 0) return fail(CRAG_EINVAL, "nq must be >= 0 (got %d)", nq);
+    if (k <= 0 || k > CRAG_MAX_K) return fail(CRAG_EINVAL, "k must be in [1, %d] (got %d)", CRAG_MAX_K, k);
+    if (nq > 0 && (!queries || !out_ids || !out_scores || !out_counts))
+        return fail(CRAG_EINVAL, "queries / out_ids / out_scores / out_counts must not be NULL");
+    if (mask) {
+        const int64_t need = ((ix->size + 31) / 32) * 4;
+        if (mask_stride != 0 && (mask_stride % 4 != 0 || mask_stride < need))
+            return fail(CRAG_EINVAL, "mask_stride must be 0 or a multiple of 4 >= %lld (got %lld)",
+                        (long long)need, (long long)mask_stride);
+        if (((uintptr_t)mask) & 3) return fail(CRAG_EINVAL, "row_mask must be 4-byte aligned");
+    }
+    return CRAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *crag_last_error(void) { return g_err; }
+
+const char *crag_version(void) { return "cadence-rag_amd dense lane 0.1 (gfx950)"; }
+
+int crag_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
+    if (!out) return fail(CRAG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (dim <= 0 || dim > CRAG_DIM) return fail(CRAG_EINVAL, "dim must be in [1, %d] (got %d)", CRAG_DIM, dim);
+    if (capacity <= 0) return fail(CRAG_EINVAL, "capacity must be > 0 (got %lld)", (long long)capacity);
+    int ndev = crag_device_count();
+    if (ndev <= 0) return fail(CRAG_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(CRAG_EINVAL, "device %d out of range [0, %d)", device, ndev);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(CRAG_EHIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CRAG_ENODEV, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    crag_index *ix = new (std::nothrow) crag_index();
+    if (!ix) return fail(CRAG_ENOMEM, "out of host memory");
+    ix->device = device;
+    ix->dim = dim;
+    ix->capacity = capacity;
+    ix->cap_rows = ((capacity + 31) / 32) * 32;
+    ix->n_cu = prop.multiProcessorCount;
+    const size_t cbytes = (size_t)ix->cap_rows * crag::DIM * sizeof(float);
+    hipError_t e;
+    if ((e = hipMalloc((void **)&ix->corpus, cbytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->inv_norm, (size_t)ix->cap_rows * sizeof(float))) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->ids, (size_t)ix->cap_rows * sizeof(int64_t))) != hipSuccess) {
+        int rc = fail(CRAG_ENOMEM, "hipMalloc for %lld rows failed: %s", (long long)ix->cap_rows,
+                      hipGetErrorString(e));
+        crag_index_destroy(ix);
+        return rc;
+    }
+    // padding rows of the last tile must read as "never eligible" and finite
+    if ((e = hipMemset(ix->inv_norm, 0, (size_t)ix->cap_rows * sizeof(float))) != hipSuccess ||
+        (e = hipMemset(ix->corpus, 0, cbytes)) != hipSuccess) {
+        int rc = fail(CRAG_EHIP, "hipMemset failed: %s", hipGetErrorString(e));
+        crag_index_destroy(ix);
+        return rc;
+    }
+    *out = ix;
+    return CRAG_OK;
+}
+
+int crag_index_destroy(crag_index *ix) {
+    if (!ix) return CRAG_OK;
+    DeviceGuard guard(ix->device);
+    (void)hipDeviceSynchronize();
+    for (auto &t : ix->ev_pool) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+        (void)hipEventDestroy(t.e2);
+    }
+    if (ix->corpus) (void)hipFree(ix->corpus);
+    if (ix->inv_norm) (void)hipFree(ix->inv_norm);
+    if (ix->ids) (void)hipFree(ix->ids);
+    ix->qtiles.release();
+    ix->partial.release();
+    ix->stage_q.release();
+    ix->stage_rows.release();
+    ix->stage_ids.release();
+    ix->stage_mask.release();
+    ix->stage_out.release();
+    ix->scratch.release();
+    delete ix;
+    return CRAG_OK;
+}
+
+int64_t crag_index_size(const crag_index *ix) { return ix ? ix->size : -1; }
+int64_t crag_index_capacity(const crag_index *ix) { return ix ? ix->capacity : -1; }
+int crag_index_dim(const crag_index *ix) { return ix ? ix->dim : -1; }
+
+static int store_rows_locked(crag_index *ix, int64_t pos, const float *rows, int64_t n) {
+    // chunked so that host staging stays bounded (64 Ki rows = 256 MiB at dim 1024)
+    const int64_t CH = 65536;
+    const bool dev = is_device_ptr(rows);
+    for (int64_t o = 0; o < n; o += CH) {
+        const int64_t m = (n - o < CH) ? (n - o) : CH;
+        const float *src = rows + (size_t)o * ix->dim;
+        if (!dev) {
+            int rc = ix->stage_rows.ensure((size_t)m * ix->dim * sizeof(float));
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(ix->stage_rows.p, src, (size_t)m * ix->dim * sizeof(float), hipMemcpyHostToDevice));
+            src = (const float *)ix->stage_rows.p;
+        }
+        HIP_TRY(crag::launch_store_rows(src, ix->dim, pos + o, m, ix->corpus, ix->inv_norm, 0));
+        if (!dev) HIP_TRY(hipStreamSynchronize(0));  // staging buffer is reused by the next chunk
+    }
+    HIP_TRY(hipStreamSynchronize(0));
+    return CRAG_OK;
+}
+
+int crag_index_add(crag_index *ix, const float *rows, const int64_t *ids, int64_t n) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    if (n < 0) return fail(CRAG_EINVAL, "n must be >= 0");
+    if (n == 0) return CRAG_OK;
+    if (!rows) return fail(CRAG_EINVAL, "rows is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (ix->size + n > ix->capacity)
+        return fail(CRAG_ENOMEM, "capacity exceeded: size %lld + %lld > %lld", (long long)ix->size,
+                    (long long)n, (long long)ix->capacity);
+    if (ix->size + n >= (int64_t)0xfffffff0ll) return fail(CRAG_ENOMEM, "more than 2^32 rows per index");
+    DeviceGuard guard(ix->device);
+    const int64_t pos = ix->size;
+    int rc = store_rows_locked(ix, pos, rows, n);
+    if (rc) return rc;
+    if (ids) {
+        HIP_TRY(hipMemcpy(ix->ids + pos, ids, (size_t)n * sizeof(int64_t),
+                          is_device_ptr(ids) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(crag::launch_fill_ids(ix->ids, pos, n, pos, 0));
+        HIP_TRY(hipStreamSynchronize(0));
+    }
+    ix->size = pos + n;
+    return CRAG_OK;
+}
+
+int crag_index_update(crag_index *ix, int64_t pos, const float *rows, int64_t n) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    if (n < 0 || pos < 0) return fail(CRAG_EINVAL, "pos and n must be >= 0");
+    if (n == 0) return CRAG_OK;
+    if (!rows) return fail(CRAG_EINVAL, "rows is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (pos + n > ix->size)
+        return fail(CRAG_EINVAL, "update range [%lld, %lld) exceeds size %lld", (long long)pos,
+                    (long long)(pos + n), (long long)ix->size);
+    DeviceGuard guard(ix->device);
+    return store_rows_locked(ix, pos, rows, n);
+}
+
+int crag_index_get_rows(crag_index *ix, int64_t pos, int64_t n, float *rows, int64_t *ids) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    if (n < 0 || pos < 0) return fail(CRAG_EINVAL, "pos and n must be >= 0");
+    if (n == 0) return CRAG_OK;
+    if (!rows) return fail(CRAG_EINVAL, "rows is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (pos + n > ix->size)
+        return fail(CRAG_EINVAL, "range [%lld, %lld) exceeds size %lld", (long long)pos,
+                    (long long)(pos + n), (long long)ix->size);
+    DeviceGuard guard(ix->device);
+    const bool dev = is_device_ptr(rows);
+    const int64_t CH = 65536;
+    for (int64_t o = 0; o < n; o += CH) {
+        const int64_t m = (n - o < CH) ? (n - o) : CH;
+        float *dst = rows + (size_t)o * ix->dim;
+        float *ddst = dst;
+        if (!dev) {
+            int rc = ix->stage_rows.ensure((size_t)m * ix->dim * sizeof(float));
+            if (rc) return rc;
+            ddst = (float *)ix->stage_rows.p;
+        }
+        HIP_TRY(crag::launch_load_rows(ix->corpus, ix->dim, pos + o, m, ddst, 0));
+        if (!dev)
+            HIP_TRY(hipMemcpy(dst, ddst, (size_t)m * ix->dim * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipStreamSynchronize(0));
+    if (ids)
+        HIP_TRY(hipMemcpy(ids, ix->ids + pos, (size_t)n * sizeof(int64_t),
+                          is_device_ptr(ids) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost));
+    return CRAG_OK;
+}
+
+int crag_index_count_eligible(crag_index *ix, const uint8_t *row_mask, int64_t *out_count) {
+    if (!ix || !out_count) return fail(CRAG_EINVAL, "index / out_count is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    *out_count = 0;
+    if (ix->size == 0) return CRAG_OK;
+    const uint32_t *dmask = nullptr;
+    if (row_mask) {
+        if (((uintptr_t)row_mask) & 3) return fail(CRAG_EINVAL, "row_mask must be 4-byte aligned");
+        const size_t mbytes = (size_t)((ix->size + 31) / 32) * 4;
+        if (is_device_ptr(row_mask)) {
+            dmask = (const uint32_t *)row_mask;
+        } else {
+            int rc = ix->stage_mask.ensure(mbytes);
+            if (rc) return rc;
+            // the caller's buffer may end at ceil(size/8) bytes: copy only that much
+            const size_t have = (size_t)((ix->size + 7) / 8);
+            HIP_TRY(hipMemset(ix->stage_mask.p, 0, mbytes));
+            HIP_TRY(hipMemcpy(ix->stage_mask.p, row_mask, have, hipMemcpyHostToDevice));
+            dmask = (const uint32_t *)ix->stage_mask.p;
+        }
+    }
+    int rc = ix->scratch.ensure(sizeof(unsigned long long));
+    if (rc) return rc;
+    HIP_TRY(hipMemset(ix->scratch.p, 0, sizeof(unsigned long long)));
+    HIP_TRY(crag::launch_count_eligible(ix->inv_norm, ix->size, dmask, (unsigned long long *)ix->scratch.p, 0));
+    unsigned long long c = 0;
+    HIP_TRY(hipMemcpy(&c, ix->scratch.p, sizeof(c), hipMemcpyDeviceToHost));
+    *out_count = (int64_t)c;
+    return CRAG_OK;
+}
+
+int crag_index_search_async(crag_index *ix, const float *d_queries, int nq, int k,
+                            const uint8_t *d_row_mask, int64_t mask_stride, int64_t *d_out_ids,
+                            float *d_out_scores, int32_t *d_out_counts, void *stream) {
+    int rc = check_search_args(ix, d_queries, nq, k, d_row_mask, mask_stride, d_out_ids, d_out_scores,
+                               d_out_counts);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    return search_device(ix, d_queries, nq, k, d_row_mask, mask_stride, d_out_ids, d_out_scores,
+                         d_out_counts, (hipStream_t)stream);
+}
+
+int crag_index_search(crag_index *ix, const float *queries, int nq, int k, const uint8_t *row_mask,
+                      int64_t mask_stride, int64_t *out_ids, float *out_scores, int32_t *out_counts) {
+    int rc = check_search_args(ix, queries, nq, k, row_mask, mask_stride, out_ids, out_scores, out_counts);
+    if (rc) return rc;
+    if (nq == 0) return CRAG_OK;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+
+    const float *dq = queries;
+    if (!is_device_ptr(queries)) {
+        const size_t b = (size_t)nq * ix->dim * sizeof(float);
+        if ((rc = ix->stage_q.ensure(b))) return rc;
+        HIP_TRY(hipMemcpy(ix->stage_q.p, queries, b, hipMemcpyHostToDevice));
+        dq = (const float *)ix->stage_q.p;
+    }
+    const uint8_t *dm = row_mask;
+    int64_t dstride = mask_stride;
+    if (row_mask && !is_device_ptr(row_mask)) {
+        const size_t words = (size_t)((ix->size + 31) / 32);
+        const size_t row_b = words * 4;
+        const int nmask = mask_stride ? nq : 1;
+        if ((rc = ix->stage_mask.ensure(row_b * nmask))) return rc;
+        HIP_TRY(hipMemset(ix->stage_mask.p, 0, row_b * nmask));
+        const size_t have = (size_t)((ix->size + 7) / 8);
+        if (mask_stride == 0) {
+            HIP_TRY(hipMemcpy(ix->stage_mask.p, row_mask, have, hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(hipMemcpy2D(ix->stage_mask.p, row_b, row_mask, (size_t)mask_stride, have, nq,
+                                hipMemcpyHostToDevice));
+            dstride = (int64_t)row_b;
+        }
+        dm = (const uint8_t *)ix->stage_mask.p;
+    }
+    const bool ids_dev = is_device_ptr(out_ids), sc_dev = is_device_ptr(out_scores),
+               ct_dev = is_device_ptr(out_counts);
+    const size_t b_ids = (size_t)nq * k * sizeof(int64_t), b_sc = (size_t)nq * k * sizeof(float),
+                 b_ct = (size_t)nq * sizeof(int32_t);
+    if ((rc = ix->stage_out.ensure(b_ids + b_sc + b_ct + 64))) return rc;
+    char *so = (char *)ix->stage_out.p;
+    int64_t *d_ids = ids_dev ? out_ids : (int64_t *)so;
+    float *d_sc = sc_dev ? out_scores : (float *)(so + b_ids);
+    int32_t *d_ct = ct_dev ? out_counts : (int32_t *)(so + b_ids + b_sc);
+
+    rc = search_device(ix, dq, nq, k, dm, dstride, d_ids, d_sc, d_ct, 0);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(0));
+    if (!ids_dev) HIP_TRY(hipMemcpy(out_ids, d_ids, b_ids, hipMemcpyDeviceToHost));
+    if (!sc_dev) HIP_TRY(hipMemcpy(out_scores, d_sc, b_sc, hipMemcpyDeviceToHost));
+    if (!ct_dev) HIP_TRY(hipMemcpy(out_counts, d_ct, b_ct, hipMemcpyDeviceToHost));
+    return CRAG_OK;
+}
+
+int crag_merge_topk(int device, const int64_t *d_ids, const float *d_scores, const int32_t *d_counts,
+                    int n_lists, int nq, int k, int64_t *d_out_ids, float *d_out_scores,
+                    int32_t *d_out_counts, void *stream) {
+    if (!d_ids || !d_scores || !d_counts || !d_out_ids || !d_out_scores || !d_out_counts)
+        return fail(CRAG_EINVAL, "NULL pointer argument");
+    if (n_lists <= 0 || nq < 0 || k <= 0 || k > CRAG_MAX_K)
+        return fail(CRAG_EINVAL, "bad sizes n_lists=%d nq=%d k=%d", n_lists, nq, k);
+    if ((int64_t)n_lists * k > 4096) return fail(CRAG_EINVAL, "n_lists*k must be <= 4096");
+    if (nq == 0) return CRAG_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(CRAG_EHIP, "hipSetDevice(%d) failed", device);
+    crag::XMergeParams p;
+    p.ids = d_ids;
+    p.scores = d_scores;
+    p.counts = d_counts;
+    p.out_ids = d_out_ids;
+    p.out_scores = d_out_scores;
+    p.out_counts = d_out_counts;
+    p.n_lists = n_lists;
+    p.nq = nq;
+    p.k = k;
+    HIP_TRY(crag::launch_merge_results(p, (hipStream_t)stream));
+    return CRAG_OK;
+}
+
+int crag_index_profile_enable(crag_index *ix, int enabled) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->profiling = enabled != 0;
+    ix->ev_used = 0;
+    return CRAG_OK;
+}
+
+int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
+                            double *merge_ms_total) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    double scan = 0.0, merge = 0.0;
+    for (size_t i = 0; i < ix->ev_used; ++i) {
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventSynchronize(ix->ev_pool[i].e2));
+        HIP_TRY(hipEventElapsedTime(&a, ix->ev_pool[i].e0, ix->ev_pool[i].e1));
+        HIP_TRY(hipEventElapsedTime(&b, ix->ev_pool[i].e1, ix->ev_pool[i].e2));
+        scan += a;
+        merge += b;
+    }
+    if (n_launches) *n_launches = (int64_t)ix->ev_used;
+    if (scan_ms_total) *scan_ms_total = scan;
+    if (merge_ms_total) *merge_ms_total = merge;
+    ix->ev_used = 0;
+    return CRAG_OK;
+}
+
+int crag_index_scan_geometry(const crag_index *ix, int nq, int *workgroups, int *threads,
+                             int *query_blocks, int64_t *algorithmic_bytes_per_launch) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    const int qb = (nq + 31) / 32;
+    if (workgroups) *workgroups = scan_groups(ix);
+    if (threads) *threads = crag::SCAN_THREADS;
+    if (query_blocks) *query_blocks = qb;
+    // N*D*4 (corpus streamed once per query batch) + Q*D*4.  A batch of more than
+    // 32 queries re-streams the corpus once per 32-query block; that is NOT counted here.
+    if (algorithmic_bytes_per_launch)
+        *algorithmic_bytes_per_launch = ix->size * (int64_t)ix->dim * 4 + (int64_t)nq * ix->dim * 4;
+    return CRAG_OK;
+}
+
+}  // extern "C"

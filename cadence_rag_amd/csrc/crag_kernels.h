@@ -1,0 +1,64 @@
+// crag_kernels.h — parameter blocks and launchers shared by crag_search.hip and crag_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace crag {
+
+constexpr int TILE_ROWS = 32;                 // corpus rows per tile (= MFMA N)
+constexpr int DIM = 1024;                     // padded vector width
+constexpr int TILE_FLOATS = TILE_ROWS * DIM;  // 128 KiB per tile
+constexpr int SCAN_WAVES = 8;                 // split-K ways per workgroup
+constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+constexpr int KSLICE = DIM / SCAN_WAVES;      // 128 dims per wave
+
+struct ScanParams {
+    const float *corpus;      // tile32 layout
+    const float *inv_norm;    // [cap_rows] 1/||row||, 0 = never eligible
+    const float *qtiles;      // [q_blocks][TILE_FLOATS] normalised queries, tile32 layout
+    const uint32_t *mask;     // nullable; 32 rows per word
+    int64_t mask_stride_w;    // words between consecutive queries' masks (0 = shared)
+    uint2 *partial;           // [q_blocks][G][32][k] keys
+    int64_t n_rows;
+    int64_t cap_rows;
+    int nq;
+    int k;
+    int G;
+};
+
+struct MergeParams {
+    const uint2 *partial;
+    const int64_t *ids;       // [cap_rows] row position -> external id (nullable)
+    int64_t id_base;          // used when ids == nullptr
+    int64_t *out_ids;
+    float *out_scores;
+    int32_t *out_counts;
+    int k;
+    int G;
+};
+
+struct XMergeParams {
+    const int64_t *ids;
+    const float *scores;
+    const int32_t *counts;
+    int64_t *out_ids;
+    float *out_scores;
+    int32_t *out_counts;
+    int n_lists;
+    int nq;
+    int k;
+};
+
+hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st);
+hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st);
+hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st);
+hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
+                             float *inv_norm, hipStream_t st);
+hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
+                            hipStream_t st);
+hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, hipStream_t st);
+hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,
+                                 unsigned long long *out, hipStream_t st);
+hipError_t launch_fill_ids(int64_t *ids, int64_t pos, int64_t n, int64_t first, hipStream_t st);
+
+}  // namespace crag

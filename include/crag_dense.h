@@ -1,0 +1,124 @@
+/*
+ * crag_dense.h — C ABI of the MI355X-native dense-retrieval lane (libcrag_dense.so).
+ *
+ * This is the drop-in boundary for the reference's dense path.  The reference has no FFI
+ * today: its "interface" for this path is (a) the pgvector SQL issued by
+ *   _fetch_chunks_dense        /root/reference/app/retrieve.py:326-354
+ *   _fetch_artifacts_dense     /root/reference/app/retrieve.py:357-389
+ *   _estimate_dense_candidates /root/reference/app/retrieve.py:303-323
+ * and the per-row `UPDATE … SET embedding = CAST(:lit AS vector(1024))` of
+ *   _update_embeddings         /root/reference/app/embedding_pipeline.py:149-168
+ * and (b) the HTTP embedding gateway behind embed_texts
+ *                              /root/reference/app/embeddings.py:48-82
+ * (gateway math: P620_TRITON_QWEN3_4B_EMBEDDING_RUNBOOK.md:683-716).
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success and a negative CRAG_E* code on error
+ * (never throws); crag_last_error() returns a thread-local message for the last failure on
+ * the calling thread.  Plain pointers and sizes only — no torch / HIP types.  "dev" pointers
+ * are device (HBM) addresses on the index's device; `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  The library owns the device corpus.
+ */
+#ifndef CRAG_DENSE_H
+#define CRAG_DENSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRAG_OK 0
+#define CRAG_EINVAL (-1)   /* bad argument */
+#define CRAG_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
+#define CRAG_ENOMEM (-3)   /* capacity exceeded / allocation failed */
+#define CRAG_ENODEV (-4)   /* no usable gfx950 device */
+
+#define CRAG_MAX_K 128     /* reference uses k = 50 / 10 (retrieve.py:18-19); BASELINE asks 10..100 */
+#define CRAG_DIM 1024      /* vector(1024): alembic/versions/0001_initial_schema.py:87 */
+
+typedef struct crag_index crag_index;
+
+const char *crag_last_error(void);
+const char *crag_version(void);
+/* Number of HIP devices visible (0 if none / no driver). */
+int crag_device_count(void);
+
+/* ---- corpus: replaces the pgvector `embedding vector(1024)` column + its scan ---------- */
+
+/* Allocate an empty index for up to `capacity` rows of `dim` (<= 1024) floats on `device`.
+ * Replaces: the table column + HNSW/seq-scan storage (0001_initial_schema.py:87,98-102). */
+int crag_index_create(int device, int dim, int64_t capacity, crag_index **out);
+int crag_index_destroy(crag_index *ix);
+
+/* Append n rows ([n, dim] row-major fp32; host OR device pointer, detected) with their
+ * 64-bit ids (NULL => consecutive ids continuing from the current size).  Rows with a zero
+ * or non-finite norm are stored but never returned (pgvector gives them a NaN distance).
+ * Replaces: _update_embeddings' per-row UPDATE (embedding_pipeline.py:157-168). */
+int crag_index_add(crag_index *ix, const float *rows, const int64_t *ids, int64_t n);
+
+/* Overwrite the vectors of rows [pos, pos+n) (positions, not ids) — re-embed in place. */
+int crag_index_update(crag_index *ix, int64_t pos, const float *rows, int64_t n);
+
+/* Rows currently stored / capacity / dim. */
+int64_t crag_index_size(const crag_index *ix);
+int64_t crag_index_capacity(const crag_index *ix);
+int crag_index_dim(const crag_index *ix);
+
+/* Copy rows [pos, pos+n) back out as [n, dim] row-major fp32 (host or device pointer) and,
+ * if ids != NULL, their ids.  Bit-exact with what was added (the corpus is stored raw). */
+int crag_index_get_rows(crag_index *ix, int64_t pos, int64_t n, float *rows, int64_t *ids);
+
+/* Number of rows that can be returned for a (shared, nullable) mask: rows with a finite
+ * non-zero norm whose mask bit is set.  Replaces: _estimate_dense_candidates' COUNT(*)
+ * (retrieve.py:303-323).  mask: host or device pointer. */
+int crag_index_count_eligible(crag_index *ix, const uint8_t *row_mask, int64_t *out_count);
+
+/* Exact cosine top-k, synchronous; every pointer may be host or device (detected).
+ *   queries     [nq, dim] row-major fp32 (need not be normalised)
+ *   row_mask    nullable.  Bit (i & 7) of byte row_mask[q*mask_stride + (i >> 3)] set =>
+ *               row at position i is eligible for query q.  mask_stride = 0 => one mask
+ *               shared by all queries; otherwise a multiple of 4 bytes >= ceil(size/32)*4.
+ *               Base address 4-byte aligned.  (Encodes _build_filter_clause, retrieve.py:93-120.)
+ *   out_ids     [nq, k]  best first; -1 padded
+ *   out_scores  [nq, k]  cosine similarity = 1 - (embedding <=> q), clamped to [-1, 1]; NaN padded
+ *   out_counts  [nq]     valid entries per query (<= k)
+ * Order: descending score; equal scores by ascending row position (insertion order), which is
+ * ascending id whenever rows were added in ascending-id order, as the backfill does
+ * (`ORDER BY id`, embedding_pipeline.py:136).  The reference SQL has no tie-break at all.
+ * Replaces: _fetch_chunks_dense / _fetch_artifacts_dense `ORDER BY embedding <=> q LIMIT k`
+ * (retrieve.py:339-353, 369-388). */
+int crag_index_search(crag_index *ix, const float *queries, int nq, int k,
+                      const uint8_t *row_mask, int64_t mask_stride, int64_t *out_ids,
+                      float *out_scores, int32_t *out_counts);
+
+/* Same, all pointers DEVICE, enqueued on `stream` with no host synchronisation (the form
+ * bench.py, the multi-GPU lane and hipGraph capture use). */
+int crag_index_search_async(crag_index *ix, const float *d_queries, int nq, int k,
+                            const uint8_t *d_row_mask, int64_t mask_stride, int64_t *d_out_ids,
+                            float *d_out_scores, int32_t *d_out_counts, void *stream);
+
+/* Merge per-shard results (the multi-GPU exchange step: each rank's [nq, k] top-k after an
+ * RCCL all-gather) into the global top-k.  All pointers DEVICE.
+ *   d_ids/d_scores/d_counts  [n_lists, nq, k] / [n_lists, nq, k] / [n_lists, nq]
+ * Same ordering rule as crag_index_search (score desc, id asc). */
+int crag_merge_topk(int device, const int64_t *d_ids, const float *d_scores,
+                    const int32_t *d_counts, int n_lists, int nq, int k, int64_t *d_out_ids,
+                    float *d_out_scores, int32_t *d_out_counts, void *stream);
+
+/* Live kernel timing for bench.py's roofline: when enabled, every search records HIP events
+ * around the scan kernel on the stream it is launched on.  crag_index_profile_read sums and
+ * clears them (synchronises the events). */
+int crag_index_profile_enable(crag_index *ix, int enabled);
+int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
+                            double *merge_ms_total);
+
+/* Launch geometry of the scan kernel for the current size (for DESIGN/bench reporting). */
+int crag_index_scan_geometry(const crag_index *ix, int nq, int *workgroups, int *threads,
+                             int *query_blocks, int64_t *algorithmic_bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAG_DENSE_H */

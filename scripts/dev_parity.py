@@ -1,0 +1,47 @@
+"""Developer check: HIP search vs the CPU oracle on seeded inputs (run on the GPU box)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import oracle
+from cadence_rag_amd.dense_index import DenseIndex
+
+def run(n, nq, k, seed=0, mask_frac=None, dup=False):
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal((n, 1024), dtype=np.float32)
+    if dup and n > 10:
+        c[n // 2] = c[3]; c[n - 1] = c[3]
+    q = rng.standard_normal((nq, 1024), dtype=np.float32)
+    if dup:
+        q[0] = c[3] * 2.0
+    ix = DenseIndex(1024, capacity=n)
+    ix.add(c)
+    mask = None
+    elig = None
+    if mask_frac is not None:
+        elig = rng.random((nq, n)) < mask_frac
+        mask = DenseIndex.pack_mask(elig)
+    t = time.time()
+    ids, sc, cnt = ix.search(q, k, row_mask=mask)
+    dt = time.time() - t
+    omask = None if elig is None else np.packbits(elig, axis=-1, bitorder="little")
+    oi, os_, oc = oracle.exact_topk(q, c, k, mask=omask, mode=oracle.F64)
+    ok_ids = np.array_equal(ids, oi)
+    err = np.nanmax(np.abs(sc.astype(np.float64) - os_)) if n else 0.0
+    print(f"n={n} nq={nq} k={k} mask={mask_frac} dup={dup}: ids_equal={ok_ids} max|dscore|={err:.3e} counts_equal={np.array_equal(cnt, oc)} t={dt*1e3:.2f}ms")
+    if not ok_ids:
+        bad = np.argwhere(ids != oi)
+        print("  first mismatches:", bad[:5].tolist())
+        for qi, p in bad[:3]:
+            print("   q", qi, "pos", p, "got", ids[qi, p], sc[qi, p], "want", oi[qi, p], os_[qi, p])
+    ix.close()
+    return ok_ids
+
+if __name__ == "__main__":
+    allok = True
+    for args in [(1000, 3, 10), (257, 1, 5), (31, 2, 10), (4096, 32, 10), (20000, 33, 50), (50000, 64, 100),
+                 (100000, 32, 10)]:
+        allok &= run(*args)
+    allok &= run(5000, 8, 10, mask_frac=0.1)
+    allok &= run(5000, 8, 10, mask_frac=0.001)
+    allok &= run(3000, 4, 20, dup=True)
+    print("ALL OK" if allok else "FAILURES")
