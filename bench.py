@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — dense-lane benchmark (contract: see DESIGN.md "Measurement").
+
+A "step" is one pass of the hot path over one batch: QUERIES_PER_STEP fp32 query vectors
+(already resident in HBM) -> exact cosine top-K over this rank's 100k x 1024 fp32 corpus shard
+(BASELINE.json configs[1]) -> [N>1 only] RCCL all-gather of the per-shard top-k + on-GPU merge.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` counts the query-over-shard units all ranks processed per
+second (N=1: plain queries/sec over the 100k corpus); `config.distinct_queries_per_s` is the
+end-to-end rate of distinct queries answered over the whole N x 100k corpus.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+ROWS_PER_GPU = 100_000
+DIM = 1024
+TOPK = 10
+QUERIES_PER_STEP = 32
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def synth(rows: int, seed: int, device) -> torch.Tensor:
+    """standard normal rows, L2-normalised, fixed seed."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(rows, DIM, generator=g, dtype=torch.float32)
+    x /= x.norm(dim=1, keepdim=True)
+    return x.to(device)
+
+
+def cpu_baseline(corpus_host: np.ndarray, queries_host: np.ndarray, gpu_ids: np.ndarray):
+    """Time the CPU restatement of the reference's exact scan (oracle/, kind "port") on a bounded
+    sample of the same workload, and use its result to check recall@10 of the GPU answer."""
+    import oracle
+
+    cores = os.cpu_count() or 1
+    oracle.set_threads(1)
+    nq1 = 8
+    t0 = time.perf_counter()
+    oracle.exact_topk(queries_host[:nq1], corpus_host, TOPK, mode=oracle.F32SEQ, fast=True)
+    t1 = time.perf_counter() - t0
+    single = nq1 / t1
+    threads = min(cores, 64)
+    oracle.set_threads(threads)
+    nqa = min(len(queries_host), max(threads, 32))
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        ids_f32, _, _ = oracle.exact_topk(queries_host[:nqa], corpus_host, TOPK, mode=oracle.F32SEQ, fast=True)
+        reps += 1
+        if time.perf_counter() - t0 > 6.0 or reps >= 20:
+            break
+    ta = time.perf_counter() - t0
+    allc = reps * nqa / ta
+    # recall@10 vs the fp64 truth oracle (eval/run_eval.py:52-55 definition)
+    truth, _, _ = oracle.exact_topk(queries_host[:nqa], corpus_host, TOPK, mode=oracle.F64, fast=True)
+    hits = sum(len(set(truth[i].tolist()) & set(gpu_ids[i].tolist())) for i in range(nqa))
+    recall = hits / float(nqa * TOPK)
+    same_order = bool(np.array_equal(truth, gpu_ids[:nqa]))
+    return {
+        "value": round(allc, 2), "unit": "queries/sec", "cores": threads, "kind": "port",
+        "sample": f"{nqa} queries x {reps} reps over the same {len(corpus_host)}x{DIM} corpus, "
+                  f"top-{TOPK}; oracle/exact_scan.c built with pgvector's float flags + OpenMP",
+        "single_core_value": round(single, 2),
+    }, recall, same_order
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
+    ap.add_argument("--queries", type=int, default=QUERIES_PER_STEP)
+    ap.add_argument("--topk", type=int, default=TOPK)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # type: ignore
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cadence_rag_amd.dense_index import DenseIndex, merge_topk
+
+    rows, nq, k = args.rows_per_gpu, args.queries, args.topk
+    corpus = synth(rows, 1234 + rank, dev)
+    queries = synth(max(nq, 64), 4321, dev)[:nq].contiguous()  # same queries on every rank
+    ids = torch.arange(rank * rows, (rank + 1) * rows, dtype=torch.int64, device=dev)
+    index = DenseIndex(DIM, capacity=rows, device=local_rank)
+    index.add(corpus, ids)
+
+    out_ids = torch.empty(nq, k, dtype=torch.int64, device=dev)
+    out_sc = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    out_ct = torch.empty(nq, dtype=torch.int32, device=dev)
+    if world > 1:
+        g_ids = torch.empty(world, nq, k, dtype=torch.int64, device=dev)
+        g_sc = torch.empty(world, nq, k, dtype=torch.float32, device=dev)
+        g_ct = torch.empty(world, nq, dtype=torch.int32, device=dev)
+        f_ids = torch.empty_like(out_ids)
+        f_sc = torch.empty_like(out_sc)
+        f_ct = torch.empty_like(out_ct)
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step() -> None:
+        index.search_async(queries, k, out_ids, out_sc, out_ct, stream=stream)
+        if world > 1:  # the path's one exchange step: 12*Q*k bytes per rank over xGMI
+            dist.all_gather_into_tensor(g_ids, out_ids)
+            dist.all_gather_into_tensor(g_sc, out_sc)
+            dist.all_gather_into_tensor(g_ct, out_ct)
+            merge_topk(g_ids, g_sc, g_ct, f_ids, f_sc, f_ct, stream=stream)
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    index.profile_enable(8)  # HIP events around every 8th scan launch of the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_launch, scan_ms, merge_ms = index.profile_read()
+    index.profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        geo = index.scan_geometry(nq)
+        scan_avg_s = scan_ms / max(n_launch, 1) / 1e3
+        achieved = geo["algorithmic_bytes"] / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+        if os.path.exists(tpath) and rows == ROWS_PER_GPU and nq == QUERIES_PER_STEP:
+            try:
+                traffic = json.load(open(tpath)).get("scan_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "queries/sec @ recall@10=1.0 (exact cosine top-10, 1024-d fp32 corpus)",
+            "value": round(world * nq * args.steps / elapsed, 2),
+            "unit": "queries/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: brute-force cosine top-{k}, {rows}x{DIM} fp32 corpus "
+                            f"per GPU, {nq} queries/step resident in HBM",
+                "rows_per_gpu": rows, "rows_total": rows * world, "dim": DIM, "k": k,
+                "queries_per_step": nq,
+                "parallelism": "1 GPU" if world == 1 else f"corpus sharded x{world}, all-gather top-k merge",
+                "distinct_queries_per_s": round(nq * args.steps / elapsed, 2),
+                "encode": "not included in this step (encoder lane reported separately when built)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "crag::scan_kernel<1>", "kernel_avg_us": round(scan_avg_s * 1e6, 2),
+                "merge_avg_us": round(merge_ms / max(n_launch, 1) * 1e3, 2),
+                "algorithmic_bytes_per_launch": geo["algorithmic_bytes"],
+                "workgroups": geo["workgroups"], "launches_timed": n_launch,
+            },
+        }
+        if not args.no_cpu_baseline:
+            # rank 0's own shard result (before the cross-shard merge) vs the oracle on that shard
+            base, recall, same_order = cpu_baseline(corpus.cpu().numpy(), queries.cpu().numpy(),
+                                                    out_ids.cpu().numpy())
+            line["cpu_baseline"] = base
+            line["config"]["recall_at_10_vs_fp64_oracle"] = recall
+            line["config"]["topk_order_identical_to_oracle"] = same_order
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    index.close()
+
+
+if __name__ == "__main__":
+    main()

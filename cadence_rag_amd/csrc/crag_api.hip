@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -87,9 +88,11 @@ struct crag_index {
     float *corpus = nullptr;
     float *inv_norm = nullptr;
     int64_t *ids = nullptr;
-    DevBuf qtiles, partial, stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
+    DevBuf qtiles, partial, gbound, stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
-    bool profiling = false;
+    int pass_parity = 0;  // alternate scan direction between searches (Infinity Cache reuse)
+    int profiling = 0;      // 0 = off, N = record HIP events around every N-th search
+    int64_t prof_calls = 0;
     std::vector<EvTriple> ev_pool;
     size_t ev_used = 0;
 };
@@ -124,8 +127,14 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     const int q_blocks = (nq + 31) / 32;
     const int G = scan_groups(ix);
     int rc;
-    if ((rc = ix->qtiles.ensure((size_t)q_blocks * crag::TILE_FLOATS * sizeof(float)))) return rc;
     if ((rc = ix->partial.ensure((size_t)q_blocks * G * 32 * (size_t)k * sizeof(uint2)))) return rc;
+    {
+        const size_t gb_bytes = (size_t)q_blocks * 32 * crag::GB_CELLS * sizeof(uint32_t);
+        if (gb_bytes > ix->gbound.bytes) {  // (re)allocated buffers start zeroed; merge re-zeroes after use
+            if ((rc = ix->gbound.ensure(gb_bytes))) return rc;
+            HIP_TRY(hipMemsetAsync(ix->gbound.p, 0, ix->gbound.bytes, st));
+        }
+    }
 
     // per-workgroup corpus window must stay below the buffer-descriptor / OOB-marker limit
     const int64_t rows_per_g = (ix->size + G - 1) / G + 64;
@@ -133,23 +142,32 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         return fail(CRAG_EINVAL, "index too large for one device scan window (%lld rows)",
                     (long long)ix->size);
 
-    HIP_TRY(crag::launch_prep_queries(d_queries, nq, ix->dim, (float *)ix->qtiles.p, st));
-
     crag::ScanParams sp;
     sp.corpus = ix->corpus;
     sp.inv_norm = ix->inv_norm;
-    sp.qtiles = (const float *)ix->qtiles.p;
+    sp.queries = d_queries;
+    sp.dim = ix->dim;
     sp.mask = (const uint32_t *)d_mask;
     sp.mask_stride_w = mask_stride / 4;
     sp.partial = (uint2 *)ix->partial.p;
+    sp.gbound = (uint32_t *)ix->gbound.p;
     sp.n_rows = ix->size;
     sp.cap_rows = ix->cap_rows;
     sp.nq = nq;
     sp.k = k;
     sp.G = G;
+    sp.reverse = ix->pass_parity;
+    ix->pass_parity ^= 1;
+    if (getenv("CRAG_NO_REVERSE")) sp.reverse = 0;
+    { const char *dm = getenv("CRAG_DEBUG_MODE"); sp.debug_mode = dm ? atoi(dm) : 0; }
+    sp.debug_out = nullptr;
+    if (sp.debug_mode == 64) {
+        if ((rc = ix->scratch.ensure(4096 * 4 * sizeof(unsigned long long)))) return rc;
+        sp.debug_out = (unsigned long long *)ix->scratch.p;
+    }
 
     EvTriple *ev = nullptr;
-    if (ix->profiling) {
+    if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == 0) {
         if (ix->ev_used == ix->ev_pool.size()) {
             EvTriple t;
             HIP_TRY(hipEventCreate(&t.e0));
@@ -166,6 +184,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     crag::MergeParams mp;
     mp.partial = (const uint2 *)ix->partial.p;
     mp.ids = ix->ids;
+    mp.gbound = (uint32_t *)ix->gbound.p;
     mp.id_base = 0;
     mp.out_ids = d_out_ids;
     mp.out_scores = d_out_scores;
@@ -269,6 +288,7 @@ int crag_index_destroy(crag_index *ix) {
     if (ix->ids) (void)hipFree(ix->ids);
     ix->qtiles.release();
     ix->partial.release();
+    ix->gbound.release();
     ix->stage_q.release();
     ix->stage_rows.release();
     ix->stage_ids.release();
@@ -497,7 +517,8 @@ int crag_merge_topk(int device, const int64_t *d_ids, const float *d_scores, con
 int crag_index_profile_enable(crag_index *ix, int enabled) {
     if (!ix) return fail(CRAG_EINVAL, "index is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
-    ix->profiling = enabled != 0;
+    ix->profiling = enabled > 0 ? enabled : 0;
+    ix->prof_calls = 0;
     ix->ev_used = 0;
     return CRAG_OK;
 }
@@ -520,6 +541,14 @@ int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms
     if (scan_ms_total) *scan_ms_total = scan;
     if (merge_ms_total) *merge_ms_total = merge;
     ix->ev_used = 0;
+    return CRAG_OK;
+}
+
+int crag_debug_read_stamps(crag_index *ix, unsigned long long *out, int n_groups) {
+    if (!ix || !ix->scratch.p) return fail(CRAG_EINVAL, "no stamps");
+    DeviceGuard guard(ix->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, ix->scratch.p, (size_t)n_groups * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRAG_OK;
 }
 

@@ -11,24 +11,31 @@ constexpr int TILE_FLOATS = TILE_ROWS * DIM;  // 128 KiB per tile
 constexpr int SCAN_WAVES = 8;                 // split-K ways per workgroup
 constexpr int SCAN_THREADS = SCAN_WAVES * 64;
 constexpr int KSLICE = DIM / SCAN_WAVES;      // 128 dims per wave
+constexpr int GB_CELLS = 32;                  // global-bound buckets per query (>= k of the pipelined kernel)
 
 struct ScanParams {
     const float *corpus;      // tile32 layout
     const float *inv_norm;    // [cap_rows] 1/||row||, 0 = never eligible
-    const float *qtiles;      // [q_blocks][TILE_FLOATS] normalised queries, tile32 layout
+    const float *queries;     // [nq, dim] row-major fp32 (raw; normalised in-kernel)
     const uint32_t *mask;     // nullable; 32 rows per word
     int64_t mask_stride_w;    // words between consecutive queries' masks (0 = shared)
     uint2 *partial;           // [q_blocks][G][32][k] keys
+    uint32_t *gbound;         // [q_blocks*32][GB_CELLS] score buckets, zero between searches
     int64_t n_rows;
     int64_t cap_rows;
     int nq;
+    int dim;
     int k;
     int G;
+    int reverse;              // walk each workgroup's range back to front (alternates per search)
+    unsigned long long *debug_out;  // stamps (debug builds of the kernel only)
+    int debug_mode;           // 1: use the unpipelined kernel for k <= 32 (A/B testing)
 };
 
 struct MergeParams {
     const uint2 *partial;
     const int64_t *ids;       // [cap_rows] row position -> external id (nullable)
+    uint32_t *gbound;         // zeroed per query after use (nullable)
     int64_t id_base;          // used when ids == nullptr
     int64_t *out_ids;
     float *out_scores;

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "crag_kernels.h"
 
 namespace crag {
@@ -140,139 +142,533 @@ struct HalfList {
 };
 
 // ------------------------------------------------------------------------------------------
-// scan kernel
+// scan kernels
 // ------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Everything the two scan kernels share: row range, buffer window, A operand, owner map.
+struct ScanCtx {
+    int lane, w, g, qb, j, h;
+    int64_t r_begin, r_end, t_begin;
+    int n_tiles;
+    bool reverse;
+    uint32_t lane_off;
+    int qloc[2];
+    bool qok[2];
+    const uint32_t *mrow[2];
+};
+
+__device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p) {
+    ScanCtx c;
+    c.lane = threadIdx.x & 63;
+    c.w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    c.g = blockIdx.x;
+    c.qb = blockIdx.y;
+    c.j = c.lane & 31;
+    c.h = c.lane >> 5;
+    // this workgroup's row range, balanced in units of 8 rows (one 128-B line per k-quad)
+    const int64_t n8 = (p.n_rows + 7) >> 3;
+    c.r_begin = ((n8 * c.g) / p.G) << 3;
+    c.r_end = ((n8 * (c.g + 1)) / p.G) << 3;
+    if (c.r_end > p.n_rows) c.r_end = p.n_rows;
+    c.t_begin = c.r_begin >> 5;
+    const int64_t t_end = (c.r_end > c.r_begin) ? ((c.r_end + 31) >> 5) : c.t_begin;
+    c.n_tiles = (int)(t_end - c.t_begin);
+    c.reverse = p.reverse != 0;
+    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.lane * 16);
+    // after the LDS reduction this wave holds accumulator registers r = 2w, 2w+1 ->
+    // query (r&3) + 8*(r>>2) + 4*h of the block, corpus row j of the tile
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * c.w + e;
+        c.qloc[e] = (r & 3) + 8 * (r >> 2) + 4 * c.h;
+        const int qglob = c.qb * 32 + c.qloc[e];
+        c.qok[e] = qglob < p.nq;
+        c.mrow[e] = p.mask ? p.mask + (size_t)(c.qok[e] ? qglob : 0) * (size_t)p.mask_stride_w : nullptr;
+    }
+    return c;
+}
+
+// byte offset of this lane's first load of tile `ti` (relative to the workgroup window), or an
+// out-of-range marker when the lane's row is not ours / the tile does not exist: the buffer
+// range check then returns zeros without touching memory
+// `step` counts tiles in processing order; a reversed pass walks the range back to front so that
+// the tail of the previous pass is still in the Infinity Cache (boustrophedon streaming)
+__device__ __forceinline__ int tile_of(const ScanCtx &c, int step) { return c.reverse ? c.n_tiles - 1 - step : step; }
+
+__device__ __forceinline__ uint32_t tile_voff(const ScanCtx &c, int step) {
+    const int ti = tile_of(c, step);
+    const int64_t row = (c.t_begin + ti) * 32 + c.j;
+    const bool valid = (step < c.n_tiles) && (row >= c.r_begin) && (row < c.r_end);
+    return valid ? (uint32_t)ti * (uint32_t)(TILE_FLOATS * 4) + c.lane_off : 0x80000000u;
+}
+
+// A operand: this wave's K slice of the (up to) 32 queries of block qb, normalised in-kernel.
+// Lane (i = lane&31, h = lane>>5) holds q[i][128w + 8s + 4h + 0..3] in a[s] — the same k
+// permutation the tile32 corpus layout gives the B operand.  A zero / non-finite query becomes
+// NaN so none of its scores is ever eligible.  `red` is 2 KiB of LDS scratch.
+__device__ __forceinline__ void load_queries(const ScanParams &p, const ScanCtx &c, f32x4 (&a)[16],
+                                             double *red) {
+    const int qi = c.qb * 32 + c.j;
+    const bool have = qi < p.nq;
+    const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int col = c.w * KSLICE + 8 * s + 4 * c.h;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (have) {
+            if ((p.dim & 3) == 0) {
+                if (col < p.dim) v = *reinterpret_cast<const f32x4 *>(qrow + col);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                    if (col + cc < p.dim) v[cc] = qrow[col + cc];
+            }
+        }
+        a[s] = v;
+    }
+    double ss = 0.0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ss += (double)a[s][cc] * (double)a[s][cc];
+    ss += __shfl_xor(ss, 32);
+    if (c.h == 0) red[c.w * 32 + c.j] = ss;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < SCAN_WAVES; ++ww) tot += red[ww * 32 + c.j];
+    __syncthreads();
+    const bool ok = (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
+    const double inv = ok ? 1.0 / sqrt(tot) : (double)__uint_as_float(0x7fc00000u);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a[s][cc] = (float)((double)a[s][cc] * inv);
+}
+
+// score -> key for one owned (query, row) pair
+__device__ __forceinline__ void make_key(float dot, float inv_row, bool ok, int64_t row, uint32_t &khi,
+                                         uint32_t &klo) {
+    float sc = dot * inv_row;
+    sc = fminf(fmaxf(sc, -1.f), 1.f);  // pgvector clamps the similarity to [-1, 1]
+    ok = ok && (dot == dot);
+    khi = ok ? f2ord(sc) : 0u;
+    klo = ok ? ~(uint32_t)row : 0u;
+}
+
+template <int S>
+__device__ __forceinline__ void write_lists(const ScanParams &p, const ScanCtx &c, const HalfList<S> (&list)[2]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (!c.qok[e]) continue;
+        uint2 *dst = p.partial + (((size_t)c.qb * p.G + c.g) * 32 + c.qloc[e]) * (size_t)p.k;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int pos = s * 32 + c.j;
+            if (pos < p.k) dst[pos] = make_uint2(list[e].hi[s], list[e].lo[s]);
+        }
+    }
+}
+
+#define CRAG_MFMA(A_, B_, ACC_) __builtin_amdgcn_mfma_f32_32x32x2f32((A_), __uint_as_float(B_), (ACC_), 0, 0, 0)
+
+// ---- generic kernel (any S): MFMA phase, then reduction + selection, one barrier per tile ----
 template <int S>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     __shared__ float2 slab[2][SCAN_WAVES][8][64];  // 64 KiB: [buf][producer wave][reg pair][lane]
+    const ScanCtx c = make_ctx(p);
+    const int lane = c.lane, w = c.w, j = c.j;
 
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int g = blockIdx.x, qb = blockIdx.y;
-    const int j = lane & 31, h = lane >> 5;
-
-    // this workgroup's row range, balanced in units of 8 rows (one 128-B line per k-quad)
-    const int64_t n8 = (p.n_rows + 7) >> 3;
-    const int64_t r_begin = ((n8 * g) / p.G) << 3;
-    int64_t r_end = ((n8 * (g + 1)) / p.G) << 3;
-    if (r_end > p.n_rows) r_end = p.n_rows;
-    const int64_t t_begin = r_begin >> 5;
-    const int64_t t_end = (r_end > r_begin) ? ((r_end + 31) >> 5) : t_begin;
-    const int n_tiles = (int)(t_end - t_begin);
-
-    // A operand: this wave's K slice of the 32 normalised queries of block qb
-    f32x4 a[16];
-    {
-        const f32x4 *qa =
-            reinterpret_cast<const f32x4 *>(p.qtiles + (size_t)qb * TILE_FLOATS + w * (KSLICE * 32)) + lane;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) a[s] = qa[s * 64];
-        // drain here, with the compiler's own builtin, so that its vmcnt scoreboard is empty
-        // before the streaming loop: otherwise the loop-head merge keeps a conservative
-        // vmcnt(4) on the A registers in every iteration and drains the prefetch ring
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    }
-
-    // corpus window of this workgroup as a buffer resource: loads past the last tile, and the
-    // lanes of rows that belong to a neighbouring workgroup, are dropped by the range check
-    const float *wg_base = p.corpus + (size_t)t_begin * TILE_FLOATS;
+    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(wg_base), 0, (int)((uint32_t)n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
-    const uint32_t OOB = 0x80000000u;
-    const uint32_t lane_off = (uint32_t)(w * (KSLICE * 32 * 4) + lane * 16);
-
-    auto tile_voff = [&](int ti) -> uint32_t {  // ti = tile index relative to t_begin
-        const int64_t row = (t_begin + ti) * 32 + j;
-        const bool valid = (ti < n_tiles) && (row >= r_begin) && (row < r_end);
-        return valid ? (uint32_t)ti * (uint32_t)(TILE_FLOATS * 4) + lane_off : OOB;
-    };
+        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
 
     u32x4 b[16];
     {
-        const uint32_t v0 = tile_voff(0);
+        const uint32_t v0 = tile_voff(c, 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
     }
+    f32x4 a[16];
+    load_queries(p, c, a, reinterpret_cast<double *>(&slab[0][0][0][0]));
+    // drain with the compiler's own builtin so its vmcnt scoreboard is empty at the loop head:
+    // otherwise the loop-head merge keeps a conservative wait on the A registers in every
+    // iteration and drains the prefetch ring
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
     HalfList<S> list[2];
     list[0].clear();
     list[1].clear();
 
-    // owner bookkeeping: after the LDS reduction this wave holds accumulator registers
-    // r = 2w, 2w+1 -> query (r&3) + 8*(r>>2) + 4*h of the block, corpus row j of the tile
-    int qloc[2];
-    bool qok[2];
-    const uint32_t *mrow[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int r = 2 * w + e;
-        qloc[e] = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int qglob = qb * 32 + qloc[e];
-        qok[e] = qglob < p.nq;
-        mrow[e] = p.mask ? p.mask + (size_t)(qok[e] ? qglob : 0) * (size_t)p.mask_stride_w : nullptr;
-    }
-
     int buf = 0;
-    for (int ti = 0; ti < n_tiles; ++ti) {
-        const uint32_t vnext = tile_voff(ti + 1);
-        const int64_t row = (t_begin + ti) * 32 + j;
-        // epilogue operands, consumed ~4k cycles from now
+    for (int ti = 0; ti < c.n_tiles; ++ti) {
+        const uint32_t vnext = tile_voff(c, ti + 1);
+        const int64_t tile = c.t_begin + tile_of(c, ti);
+        const int64_t row = tile * 32 + j;
         const float inv_cur = p.inv_norm[row];  // row < cap_rows: the tile exists
         uint32_t mword[2] = {0xffffffffu, 0xffffffffu};
         if (p.mask) {
-            mword[0] = mrow[0][t_begin + ti];
-            mword[1] = mrow[1][t_begin + ti];
+            mword[0] = c.mrow[0][tile];
+            mword[1] = c.mrow[1][tile];
         }
-
-        // 16 steps of {4 MFMA on b[s]; refill b[s] from the next tile}.  The sched_barrier pins
-        // that interleave: every load is issued 15 steps (one whole tile of MFMAs) before its
-        // use, so 16 KiB per wave / 128 KiB per CU are always in flight.
+        // 16 steps of {4 MFMA on b[s]; refill b[s] from the next tile}; the sched_barrier pins the
+        // interleave so every load is issued one whole tile of MFMAs before its use
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][0], __uint_as_float(b[s][0]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][1], __uint_as_float(b[s][1]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][2], __uint_as_float(b[s][2]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][3], __uint_as_float(b[s][3]), acc, 0, 0, 0);
+            acc = CRAG_MFMA(a[s][0], b[s][0], acc);
+            acc = CRAG_MFMA(a[s][1], b[s][1], acc);
+            acc = CRAG_MFMA(a[s][2], b[s][2], acc);
+            acc = CRAG_MFMA(a[s][3], b[s][3], acc);
             b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-
         // split-K reduction through LDS (double-buffered: one barrier per tile)
 #pragma unroll
         for (int pr = 0; pr < 8; ++pr) slab[buf][w][pr][lane] = make_float2(acc[2 * pr], acc[2 * pr + 1]);
         __syncthreads();
-        float d0 = 0.f, d1 = 0.f;
+        float d[2] = {0.f, 0.f};
 #pragma unroll
         for (int ww = 0; ww < SCAN_WAVES; ++ww) {  // fixed order: bit-reproducible
             const float2 v = slab[buf][ww][w][lane];
-            d0 += v.x;
-            d1 += v.y;
+            d[0] += v.x;
+            d[1] += v.y;
         }
         buf ^= 1;
-
-        const bool row_ok = (row >= r_begin) && (row < r_end) && (inv_cur > 0.f);
+        const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float raw = (e == 0 ? d0 : d1);
-            float sc = raw * inv_cur;
-            sc = fminf(fmaxf(sc, -1.f), 1.f);  // pgvector clamps the similarity to [-1, 1]
-            const bool ok = row_ok && qok[e] && ((mword[e] >> j) & 1u) && (raw == raw);
-            const uint32_t khi = ok ? f2ord(sc) : 0u;
-            const uint32_t klo = ok ? ~(uint32_t)row : 0u;
+            uint32_t khi, klo;
+            make_key(d[e], inv_cur, row_ok && c.qok[e] && ((mword[e] >> j) & 1u), row, khi, klo);
             list[e].insert(khi, klo, p.k, lane);
         }
     }
+    write_lists<S>(p, c, list);
+}
 
-    // per-workgroup result: partial[qb][g][query][k]
+// ---- pipelined kernel (k <= 32): the split-K reduction and the top-k selection of tile t-1 are
+// cut into small ops (<= ~12 VALU each) and spread over the MFMA slots of tile t, so that the
+// matrix pipe never waits for the LDS round trip or the sorting network.  The queries are used
+// raw as the A operand; 1/||q|| is applied when a score becomes a key. ------------------------
+struct PipeSel {  // both owned register lists (e = 0, 1) move through the network together
+    uint32_t h[2], l[2];    // keys in flight (batch, later the merged bitonic sequence)
+    uint32_t ph[2], pl[2];  // partner keys of the swizzle issued in the previous op
+    uint32_t th[2], tl[2];  // current k-th key of each list, broadcast over its half-wave
+    uint32_t pub[2];        // best score already published to the global bound (lane 0 of the half)
+    bool active;            // wave-uniform: this batch has a key that beats a current k-th
+};
+
+template <int X>
+__device__ __forceinline__ void net_issue(PipeSel &n) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        if (!qok[e]) continue;
-        uint2 *dst = p.partial + (((size_t)qb * p.G + g) * 32 + qloc[e]) * (size_t)p.k;
+        n.ph[e] = swz_xor<X>(n.h[e]);
+        n.pl[e] = swz_xor<X>(n.l[e]);
+    }
+}
+template <int BIT>
+__device__ __forceinline__ void net_consume(PipeSel &n, int lane) {
+    const bool want_max = !(lane & BIT);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int pos = s * 32 + j;
-            if (pos < p.k) dst[pos] = make_uint2(list[e].hi[s], list[e].lo[s]);
+    for (int e = 0; e < 2; ++e) {
+        const bool keep = (mk64(n.h[e], n.l[e]) > mk64(n.ph[e], n.pl[e])) == want_max;
+        n.h[e] = keep ? n.h[e] : n.ph[e];
+        n.l[e] = keep ? n.l[e] : n.pl[e];
+    }
+}
+
+// the network as (xor distance, direction bit) per stage: 15 sort stages (0..14), then after the
+// merge-split with the list 5 bitonic-merge stages (16..20)
+template <int ST> struct SortStage;
+#define CRAG_STAGE(ST_, X_, B_) \
+    template <> struct SortStage<ST_> { static constexpr int X = X_, BIT = B_; };
+CRAG_STAGE(0, 1, 1)
+CRAG_STAGE(1, 3, 2)
+CRAG_STAGE(2, 1, 1)
+CRAG_STAGE(3, 7, 4)
+CRAG_STAGE(4, 2, 2)
+CRAG_STAGE(5, 1, 1)
+CRAG_STAGE(6, 15, 8)
+CRAG_STAGE(7, 4, 4)
+CRAG_STAGE(8, 2, 2)
+CRAG_STAGE(9, 1, 1)
+CRAG_STAGE(10, 31, 16)
+CRAG_STAGE(11, 8, 8)
+CRAG_STAGE(12, 4, 4)
+CRAG_STAGE(13, 2, 2)
+CRAG_STAGE(14, 1, 1)
+CRAG_STAGE(16, 16, 16)
+CRAG_STAGE(17, 8, 8)
+CRAG_STAGE(18, 4, 4)
+CRAG_STAGE(19, 2, 2)
+CRAG_STAGE(20, 1, 1)
+#undef CRAG_STAGE
+
+struct PipeTile {  // epilogue operands of the tile whose partial sums sit in the slab
+    uint32_t nrow;      // ~row position (the low key word)
+    float scale[2];     // inv_norm[row] * 1/||q_e||, or 0 when (row, query e) is not eligible
+    uint32_t tauh[2];   // global lower bound on the k-th best score of query e (orderable bits)
+};
+
+struct PipeState {
+    float2 rd[SCAN_WAVES];
+    float d[2];
+    HalfList<1> list[2];
+    PipeSel n;
+};
+
+constexpr int PIPE_OPS = 28;
+
+// background op OP of the tile-(t-1) epilogue; placed after MFMA 2*OP of tile t
+template <int OP>
+__device__ __forceinline__ void pipe_bg(const ScanParams &p, const ScanCtx &c, float2 (*slab)[SCAN_WAVES][8][64],
+                                        int rbuf, const PipeTile &pt, PipeState &st) {
+    const int lane = c.lane;
+    PipeSel &n = st.n;
+    if constexpr (OP == 0) {
+        __syncthreads();  // every wave's partial accumulators of the previous tile are in the slab
+    } else if constexpr (OP == 1) {
+#pragma unroll
+        for (int ww = 0; ww < SCAN_WAVES; ++ww) st.rd[ww] = slab[rbuf][ww][c.w][lane];
+    } else if constexpr (OP == 2) {  // fixed summation order: bit-reproducible
+        st.d[0] = ((st.rd[0].x + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
+        st.d[1] = ((st.rd[0].y + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
+    } else if constexpr (OP == 3) {
+        st.d[0] = (((st.d[0] + st.rd[4].x) + st.rd[5].x) + st.rd[6].x) + st.rd[7].x;
+        st.d[1] = (((st.d[1] + st.rd[4].y) + st.rd[5].y) + st.rd[6].y) + st.rd[7].y;
+    } else if constexpr (OP == 4 || OP == 5) {  // score -> key
+        constexpr int e = OP - 4;
+        float sc = st.d[e] * pt.scale[e];
+        sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);  // pgvector clamps the similarity to [-1, 1]
+        const bool ok = (pt.scale[e] > 0.f) && (sc == sc);
+        const uint32_t u = __float_as_uint(sc);
+        const uint32_t ord = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+        n.h[e] = ok ? ord : 0u;
+        n.l[e] = ok ? pt.nrow : 0u;
+    } else if constexpr (OP == 6) {
+        // a key matters only if it beats this workgroup's k-th AND is not below the global bound
+        const bool beats = ((mk64(n.h[0], n.l[0]) > mk64(n.th[0], n.tl[0])) && (n.h[0] >= pt.tauh[0])) ||
+                           ((mk64(n.h[1], n.l[1]) > mk64(n.th[1], n.tl[1])) && (n.h[1] >= pt.tauh[1]));
+        n.active = __any(beats);
+        if (n.active) net_issue<SortStage<0>::X>(n);
+    } else if constexpr (OP >= 7 && OP <= 20) {  // consume sort stage OP-7, issue sort stage OP-6
+        if (n.active) {
+            net_consume<SortStage<OP - 7>::BIT>(n, lane);
+            net_issue<SortStage<OP - 6>::X>(n);
+        }
+    } else if constexpr (OP == 21) {  // batch sorted descending; reverse it for the merge-split
+        if (n.active) {
+            net_consume<SortStage<14>::BIT>(n, lane);
+            net_issue<31>(n);
+        }
+    } else if constexpr (OP == 22) {  // merge-split: keep the elementwise max (bitonic), drop the min
+        if (n.active) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool gt = mk64(n.ph[e], n.pl[e]) > mk64(st.list[e].hi[0], st.list[e].lo[0]);
+                n.h[e] = gt ? n.ph[e] : st.list[e].hi[0];
+                n.l[e] = gt ? n.pl[e] : st.list[e].lo[0];
+            }
+            net_issue<SortStage<16>::X>(n);
+        }
+    } else if constexpr (OP >= 23 && OP <= 26) {  // consume merge stage OP-7, issue the next
+        if (n.active) {
+            net_consume<SortStage<OP - 7>::BIT>(n, lane);
+            net_issue<SortStage<OP - 6>::X>(n);
+        }
+    } else if constexpr (OP == 27) {
+        if (n.active) {
+            net_consume<SortStage<20>::BIT>(n, lane);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                st.list[e].hi[0] = n.h[e];
+                st.list[e].lo[0] = n.l[e];
+                const uint64_t t = st.list[e].kth(p.k, lane);
+                n.th[e] = (uint32_t)(t >> 32);
+                n.tl[e] = (uint32_t)t;
+                // publish this workgroup's best score of query e into its bucket (see gbound)
+                if ((lane & 31) == 0 && c.qok[e] && n.h[e] > n.pub[e]) {
+                    n.pub[e] = n.h[e];  // only when the head improved: ~ln(rows) times per list
+                    (void)__hip_atomic_fetch_max(p.gbound + (size_t)(c.qb * 32 + c.qloc[e]) * GB_CELLS + (c.g % p.k),
+                                                 n.h[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+// min over the 32 lanes of each half-wave, result in every lane (DPP butterflies + one swizzle)
+__device__ __forceinline__ uint32_t half_min_u32(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+    v = t < v ? t : v;
+    t = swz_xor<16>(v);
+    return t < v ? t : v;
+}
+
+template <int DBG>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
+    __shared__ float2 slab[2][SCAN_WAVES][8][64];
+    __shared__ double red[SCAN_WAVES][32];  // per-wave partial sums of squares of the 32 queries
+    const ScanCtx c = make_ctx(p);
+    const int lane = c.lane, w = c.w, j = c.j;
+    unsigned long long stampS = 0;
+    if constexpr (DBG & 64) stampS = __builtin_amdgcn_s_memrealtime();
+
+    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
+
+    u32x4 b[16];
+    {
+        const uint32_t v0 = tile_voff(c, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+    }
+    // A operand: raw queries, lane (i = lane&31, h = lane>>5) holds q[i][128w + 8s + 4h + 0..3]
+    f32x4 a[16];
+    {
+        const int qi = c.qb * 32 + j;
+        const bool have = qi < p.nq;
+        const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int col = w * KSLICE + 8 * s + 4 * c.h;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (have) {
+                if ((p.dim & 3) == 0) {
+                    if (col < p.dim) v = *reinterpret_cast<const f32x4 *>(qrow + col);
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (col + cc < p.dim) v[cc] = qrow[col + cc];
+                }
+            }
+            a[s] = v;
+        }
+        double ss = 0.0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) ss += (double)a[s][cc] * (double)a[s][cc];
+        ss += __shfl_xor(ss, 32);
+        if (c.h == 0) red[w][j] = ss;  // read after the first barrier of the tile loop
+    }
+    // drain with the compiler's own builtin so its vmcnt scoreboard is empty at the loop head:
+    // otherwise the loop-head merge keeps a conservative wait on the A registers in every
+    // iteration and drains the prefetch ring
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+
+    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+    if constexpr (DBG & 64) stamp1 = __builtin_amdgcn_s_memrealtime();
+    PipeState st;
+    st.list[0].clear();
+    st.list[1].clear();
+    st.n.active = false;
+    st.d[0] = st.d[1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) st.n.h[e] = st.n.l[e] = st.n.ph[e] = st.n.pl[e] = st.n.th[e] = st.n.tl[e] = st.n.pub[e] = 0u;
+#pragma unroll
+    for (int ww = 0; ww < SCAN_WAVES; ++ww) st.rd[ww] = make_float2(0.f, 0.f);
+    PipeTile prev;  // "no previous tile": scale 0 => every key empty, batch inactive
+    prev.nrow = 0u;
+    prev.scale[0] = prev.scale[1] = 0.f;
+    prev.tauh[0] = prev.tauh[1] = 0u;
+    float qinv[2] = {0.f, 0.f};  // 1/||q|| of the two owned queries of this half-wave
+
+    int wbuf = 0;  // slab buffer the tile now being multiplied will be written to
+    for (int ti = 0; ti < c.n_tiles; ++ti) {
+        const uint32_t vnext = tile_voff(c, ti + 1);
+        const int64_t tile = c.t_begin + tile_of(c, ti);
+        const int64_t row = tile * 32 + j;
+        const float inv_row = p.inv_norm[row];  // row < cap_rows: the tile exists
+        uint32_t mword[2] = {0xffffffffu, 0xffffffffu};
+        if (p.mask) {
+            mword[0] = c.mrow[0][tile];
+            mword[1] = c.mrow[1][tile];
+        }
+        // global bound: k buckets per query, bucket b = best score any workgroup g with g % k == b
+        // has published; k distinct rows score >= the smallest bucket, so nothing below it can be
+        // in the final top-k.  Stale values only prune less.
+        uint32_t gbv[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            gbv[e] = (j < p.k && c.qok[e])
+                         ? __hip_atomic_load(p.gbound + (size_t)(c.qb * 32 + c.qloc[e]) * GB_CELLS + j,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : 0xffffffffu;
+        PipeTile cur;
+        cur.nrow = ~(uint32_t)row;
+        cur.scale[0] = cur.scale[1] = 0.f;
+        cur.tauh[0] = cur.tauh[1] = 0u;
+
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        static_for<0, 64>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            constexpr int s = m >> 2, cc = m & 3;
+            if constexpr (!(DBG & 4)) acc = CRAG_MFMA(a[s][cc], b[s][cc], acc);
+            else acc[cc] += __uint_as_float(b[s][cc]);
+            if constexpr (cc == 3 && !(DBG & 2)) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
+            if constexpr ((m & 1) == 0 && (m >> 1) < PIPE_OPS && !(DBG & 8) && ((DBG >> 8) == 0 || (m >> 1) < (DBG >> 8))) {
+                pipe_bg<(m >> 1)>(p, c, slab, wbuf ^ 1, prev, st);
+            }
+            if constexpr (m == 5) {
+                // first tile only: the query norms (their partials were written before barrier 0)
+                if (ti == 0) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        double tot = 0.0;
+#pragma unroll
+                        for (int ww = 0; ww < SCAN_WAVES; ++ww) tot += red[ww][c.qloc[e]];
+                        const bool ok = c.qok[e] && (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
+                        qinv[e] = ok ? (float)(1.0 / sqrt(tot)) : 0.f;
+                        if (!(qinv[e] < 3.0e38f)) qinv[e] = 0.f;
+                    }
+                }
+            }
+            if constexpr (m == 57) {  // eligibility of this tile's (row, query) pairs, used next tile
+                const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_row > 0.f);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    cur.scale[e] = (row_ok && ((mword[e] >> j) & 1u)) ? inv_row * qinv[e] : 0.f;
+            }
+            if constexpr (m == 59 || m == 61) {
+                constexpr int e = (m - 59) >> 1;
+                cur.tauh[e] = half_min_u32(gbv[e]);
+                // what our own bucket already holds: publishing is pointless unless we beat it
+                const uint32_t mine = (uint32_t)__shfl((int)gbv[e], (lane & 32) | (c.g % p.k));
+                st.n.pub[e] = mine > st.n.pub[e] ? mine : st.n.pub[e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) slab[wbuf][w][pr][lane] = make_float2(acc[2 * pr], acc[2 * pr + 1]);
+        wbuf ^= 1;
+        prev = cur;
+    }
+    if constexpr (DBG & 64) stamp2 = __builtin_amdgcn_s_memrealtime();
+    if (c.n_tiles > 0) {  // drain: epilogue of the last tile
+        static_for<0, PIPE_OPS>([&](auto O) { pipe_bg<decltype(O)::value>(p, c, slab, wbuf ^ 1, prev, st); });
+    }
+    write_lists<1>(p, c, st.list);
+    if constexpr (DBG & 64) {
+        stamp0 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && p.debug_out) {
+            unsigned long long *o = p.debug_out + (size_t)blockIdx.x * 4;
+            o[0] = stampS; o[1] = stamp1; o[2] = stamp2; o[3] = stamp0;
         }
     }
 }
@@ -282,17 +678,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
 // ------------------------------------------------------------------------------------------
 constexpr int MERGE_THREADS = 256;
 constexpr int MERGE_CAP = 2048;       // candidates kept in LDS
-constexpr int MERGE_RANK_MAX = 1024;  // above this many candidates: radix-select first
+constexpr int MERGE_RANK_MAX = 512;   // above this many candidates: radix-select first
+constexpr int MERGE_HEADS = 1024;     // list heads kept in LDS for the head threshold
 constexpr int CRAG_MAX_K_ = 128;      // = CRAG_MAX_K of include/crag_dense.h
 
 __device__ __forceinline__ uint64_t key_of(uint2 v) { return mk64(v.x, v.y); }
 
+// number of histogram entries strictly above bin `tid` (256 bins, 256 threads)
+__device__ __forceinline__ int suffix_above(const int *hist, int *wave_tot, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int v = hist[tid];
+    int incl = v;  // sum of bins tid .. end-of-wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_down(incl, o);
+        if (lane + o < 64) incl += nb;
+    }
+    if (lane == 0) wave_tot[wv] = incl;
+    __syncthreads();
+    int above = incl - v;
+    for (int ww = wv + 1; ww < MERGE_THREADS / 64; ++ww) above += wave_tot[ww];
+    return above;
+}
+
 __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergeParams p) {
     __shared__ uint64_t cand[MERGE_CAP];
     __shared__ uint64_t win[CRAG_MAX_K_];
+    __shared__ __attribute__((aligned(16))) uint64_t heads[MERGE_HEADS + 8];
     __shared__ unsigned long long s_tau;
     __shared__ int s_cnt;
     __shared__ int hist[256];
+    __shared__ int wave_tot[MERGE_THREADS / 64];
+    __shared__ unsigned long long wave_max[MERGE_THREADS / 64];
     __shared__ int s_digit, s_need;
 
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -301,6 +718,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergePara
     const size_t lstride = (size_t)32 * p.k;  // entries between consecutive workgroups' lists
     const int k = p.k, n_lists = p.G;
     const int total = n_lists * k;
+    const bool use_heads = (n_lists >= k) && (n_lists <= MERGE_HEADS);
 
     if (tid == 0) {
         s_tau = 0ull;
@@ -308,23 +726,77 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergePara
     }
     __syncthreads();
 
-    // 1. every final top-k key is >= the largest k-th key of any single list
+    // 1. two lower bounds on the final k-th key: the largest k-th key of any single list, and
+    //    the k-th largest list head (k distinct entries are >= it).  Each thread owns the lists
+    //    l = tid, tid + 256, ...; the first one's leading entries are fetched up front (independent
+    //    loads) so that the walk in step 2 rarely needs a dependent round trip to memory.
+    constexpr int LEAD = 4;
+    uint64_t lead[LEAD];
+#pragma unroll
+    for (int i = 0; i < LEAD; ++i) lead[i] = 0ull;
     {
         unsigned long long m = 0ull;
         for (int l = tid; l < n_lists; l += MERGE_THREADS) {
-            const unsigned long long kk = key_of(base[(size_t)l * lstride + (k - 1)]);
+            const uint2 *lp = base + (size_t)l * lstride;
+            const unsigned long long kk = key_of(lp[k - 1]);
             m = kk > m ? kk : m;
+            if (l == tid) {
+#pragma unroll
+                for (int i = 0; i < LEAD; ++i)
+                    if (i < k) lead[i] = key_of(lp[i]);
+                if (use_heads) heads[l] = lead[0];
+            } else if (use_heads) {
+                heads[l] = key_of(lp[0]);
+            }
         }
-        if (m) atomicMax(&s_tau, m);
+        if (use_heads && tid < 8 && n_lists + tid < MERGE_HEADS + 8) heads[n_lists + tid] = 0ull;
+        // block max without 256-way contention on one LDS word
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(m, o);
+            m = other > m ? other : m;
+        }
+        if ((tid & 63) == 0) wave_max[tid >> 6] = m;
     }
     __syncthreads();
+    if (tid == 0) {
+        unsigned long long m = wave_max[0];
+        for (int i = 1; i < MERGE_THREADS / 64; ++i) m = wave_max[i] > m ? wave_max[i] : m;
+        s_tau = m;
+    }
+    __syncthreads();
+    if (use_heads) {
+        const int n_pad = (n_lists + 7) & ~7;  // heads[n_lists .. n_pad) were zeroed above
+        const ulonglong2 *h2 = reinterpret_cast<const ulonglong2 *>(heads);
+        for (int l = tid; l < n_lists; l += MERGE_THREADS) {
+            const uint64_t mine = heads[l];
+            if (mine == 0ull) continue;
+            int rank = 0;
+            for (int i = 0; i < n_pad / 2; i += 4) {  // 8 keys per iteration, 4 independent LDS reads
+                const ulonglong2 a0 = h2[i], a1 = h2[i + 1], a2 = h2[i + 2], a3 = h2[i + 3];
+                rank += (a0.x > mine) + (a0.y > mine) + (a1.x > mine) + (a1.y > mine) + (a2.x > mine) +
+                        (a2.y > mine) + (a3.x > mine) + (a3.y > mine);
+            }
+            if (rank == k - 1) atomicMax(&s_tau, (unsigned long long)mine);
+        }
+        __syncthreads();
+    }
     const uint64_t tau = s_tau;
 
-    // 2. compact the survivors into LDS
-    for (int e = tid; e < total; e += MERGE_THREADS) {
-        const int l = e / k, pos = e - l * k;
-        const uint64_t kk = key_of(base[(size_t)l * lstride + pos]);
-        if (kk != 0ull && kk >= tau) {
+    // 2. compact the survivors into LDS: lists are sorted, so walk each one only while >= tau
+    for (int l = tid; l < n_lists; l += MERGE_THREADS) {
+        const uint2 *lp = base + (size_t)l * lstride;
+        for (int pos = 0; pos < k; ++pos) {
+            uint64_t kk;
+            if (l == tid && pos < LEAD) {
+                kk = lead[0];
+#pragma unroll
+                for (int i = 1; i < LEAD; ++i)
+                    if (pos == i) kk = lead[i];
+            } else {
+                kk = key_of(lp[pos]);
+            }
+            if (kk == 0ull || kk < tau) break;
             const int idx = atomicAdd(&s_cnt, 1);
             if (idx < MERGE_CAP) cand[idx] = kk;
         }
@@ -351,15 +823,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergePara
                 for (int e = tid; e < total; e += MERGE_THREADS) {
                     const int l = e / k, pos = e - l * k;
                     const uint64_t kk = key_of(base[(size_t)l * lstride + pos]);
-                    if (kk != 0ull && (kk & pmask) == prefix)
+                    if (kk >= tau && kk != 0ull && (kk & pmask) == prefix)
                         atomicAdd(&hist[(int)((kk >> shift) & 255ull)], 1);
                 }
             }
             __syncthreads();
-            // digit d with  sum_{d'>d} hist < need <= sum_{d'>=d} hist
-            {
-                int above = 0;
-                for (int d = tid + 1; d < 256; ++d) above += hist[d];
+            {  // digit d with  sum_{d'>d} hist < need <= sum_{d'>=d} hist
+                const int above = suffix_above(hist, wave_tot, tid);
                 const int here = hist[tid];
                 if (above < need && above + here >= need) {
                     s_digit = tid;
@@ -416,6 +886,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergePara
         p.out_ids[(size_t)q * k + r] = -1;
     }
     if (tid == 0) p.out_counts[q] = count;
+    // leave the global-bound cells of this query zeroed for the next scan that uses this workspace
+    if (p.gbound && tid < GB_CELLS) p.gbound[(size_t)q * GB_CELLS + tid] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -575,7 +1047,29 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // ------------------------------------------------------------------------------------------
 hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st) {
     dim3 grid(p.G, q_blocks), block(SCAN_THREADS);
-    if (p.k <= 32)
+    if (p.k <= 32 && p.debug_mode == 2)
+        hipLaunchKernelGGL(scan_pipe_kernel<2>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 4)
+        hipLaunchKernelGGL(scan_pipe_kernel<4>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 10)
+        hipLaunchKernelGGL(scan_pipe_kernel<10>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 64)
+        hipLaunchKernelGGL(scan_pipe_kernel<64>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 258)
+        hipLaunchKernelGGL(scan_pipe_kernel<258>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 514)
+        hipLaunchKernelGGL(scan_pipe_kernel<514>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 1026)
+        hipLaunchKernelGGL(scan_pipe_kernel<1026>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 1538)
+        hipLaunchKernelGGL(scan_pipe_kernel<1538>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 1794)
+        hipLaunchKernelGGL(scan_pipe_kernel<1794>, grid, block, 0, st, p);
+    else if (p.k <= 32 && p.debug_mode == 8)
+        hipLaunchKernelGGL(scan_pipe_kernel<8>, grid, block, 0, st, p);
+    else if (p.k <= 32 && !p.debug_mode)
+        hipLaunchKernelGGL(scan_pipe_kernel<0>, grid, block, 0, st, p);
+    else if (p.k <= 32)
         hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, st, p);
     else if (p.k <= 64)
         hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, st, p);

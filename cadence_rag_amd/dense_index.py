@@ -172,8 +172,9 @@ class DenseIndex:
             ctypes.c_void_p(stream)), "crag_index_search_async")
 
     # -- profiling / reporting -------------------------------------------------------------
-    def profile_enable(self, enabled: bool = True) -> None:
-        _native.check(self._lib.crag_index_profile_enable(self._h, int(enabled)), "profile_enable")
+    def profile_enable(self, every: int = 1) -> None:
+        """Record HIP events around the scan/merge kernels of every `every`-th search (0 = off)."""
+        _native.check(self._lib.crag_index_profile_enable(self._h, int(every)), "profile_enable")
 
     def profile_read(self) -> Tuple[int, float, float]:
         n = ctypes.c_int64(0)

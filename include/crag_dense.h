@@ -107,9 +107,10 @@ int crag_merge_topk(int device, const int64_t *d_ids, const float *d_scores,
                     const int32_t *d_counts, int n_lists, int nq, int k, int64_t *d_out_ids,
                     float *d_out_scores, int32_t *d_out_counts, void *stream);
 
-/* Live kernel timing for bench.py's roofline: when enabled, every search records HIP events
- * around the scan kernel on the stream it is launched on.  crag_index_profile_read sums and
- * clears them (synchronises the events). */
+/* Live kernel timing for bench.py's roofline: enabled = N > 0 records HIP events around the scan
+ * (and merge) kernel of every N-th search, on the stream it is launched on (N = 1: every search;
+ * larger N perturbs the timed region less); 0 disables.  crag_index_profile_read sums and clears
+ * the recorded samples (synchronises the events); n_launches = number of samples. */
 int crag_index_profile_enable(crag_index *ix, int enabled);
 int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
                             double *merge_ms_total);
