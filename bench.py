@@ -118,9 +118,9 @@ def main() -> None:
     out_sc = torch.empty(nq, k, dtype=torch.float32, device=dev)
     out_ct = torch.empty(nq, dtype=torch.int32, device=dev)
     if world > 1:
-        g_ids = torch.empty(world, nq, k, dtype=torch.int64, device=dev)
-        g_sc = torch.empty(world, nq, k, dtype=torch.float32, device=dev)
-        g_ct = torch.empty(world, nq, dtype=torch.int32, device=dev)
+        g_ids = torch.empty(world * nq, k, dtype=torch.int64, device=dev)
+        g_sc = torch.empty(world * nq, k, dtype=torch.float32, device=dev)
+        g_ct = torch.empty(world * nq, dtype=torch.int32, device=dev)
         f_ids = torch.empty_like(out_ids)
         f_sc = torch.empty_like(out_sc)
         f_ct = torch.empty_like(out_ct)
@@ -133,7 +133,8 @@ def main() -> None:
             dist.all_gather_into_tensor(g_ids, out_ids)
             dist.all_gather_into_tensor(g_sc, out_sc)
             dist.all_gather_into_tensor(g_ct, out_ct)
-            merge_topk(g_ids, g_sc, g_ct, f_ids, f_sc, f_ct, stream=stream)
+            merge_topk(g_ids.view(world, nq, k), g_sc.view(world, nq, k), g_ct.view(world, nq),
+                       f_ids, f_sc, f_ct, stream=stream)
 
     def fence() -> None:
         if world > 1:
@@ -187,7 +188,7 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "crag::scan_kernel<1>", "kernel_avg_us": round(scan_avg_s * 1e6, 2),
+                "kernel": "crag::scan_pipe_kernel<0>", "kernel_avg_us": round(scan_avg_s * 1e6, 2),
                 "merge_avg_us": round(merge_ms / max(n_launch, 1) * 1e3, 2),
                 "algorithmic_bytes_per_launch": geo["algorithmic_bytes"],
                 "workgroups": geo["workgroups"], "launches_timed": n_launch,

@@ -138,6 +138,8 @@ class DenseIndex:
         (NaN pad), counts [nq] int32).  row_mask: packed bits from pack_mask(), shape
         [bytes] (shared) or [nq, bytes] (per query)."""
         ptr, nq, keep = _as_f32_2d(queries, self.dim, "queries")
+        if not 1 <= int(k) <= _native.CRAG_MAX_K:
+            raise ValueError(f"k must be in [1, {_native.CRAG_MAX_K}] (got {k})")
         out_ids = np.empty((nq, k), dtype=np.int64)
         out_scores = np.empty((nq, k), dtype=np.float32)
         out_counts = np.empty((nq,), dtype=np.int32)

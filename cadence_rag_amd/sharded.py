@@ -1,0 +1,66 @@
+"""Multi-GPU dense search: one process per GPU, the corpus sharded by rows, per-shard exact top-k,
+then the path's single exchange step — an all-gather of (ids, scores, counts)[nq, k] (12*nq*k
+bytes per rank; RCCL over xGMI when the group's backend is "nccl") — and a k-way merge on every
+rank (crag_merge_topk on the GPU).  No reference counterpart: the reference has no parallelism
+(SURVEY.md 2); ordering rule as in crag_index_search (score desc, id asc).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .dense_index import DenseIndex, merge_topk
+
+
+def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row shard [lo, hi) of rank `rank`: sizes differ by at most one row."""
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class ShardedSearch:
+    def __init__(self, index: Optional[DenseIndex], group=None,
+                 local_search: Optional[Callable] = None, merge: Optional[Callable] = None) -> None:
+        """local_search(queries, k) -> (ids, scores, counts) tensors and merge(ids, scores, counts)
+        -> (ids, scores, counts) default to the HIP paths; tests inject CPU stand-ins over gloo."""
+        self.index = index
+        self.group = group
+        self._local = local_search or self._hip_local
+        self._merge = merge or self._hip_merge
+
+    def _hip_local(self, queries: torch.Tensor, k: int):
+        if self.index is None:
+            raise RuntimeError("ShardedSearch needs a DenseIndex (no CPU fallback)")
+        nq = queries.shape[0]
+        ids = torch.empty(nq, k, dtype=torch.int64, device=queries.device)
+        sc = torch.empty(nq, k, dtype=torch.float32, device=queries.device)
+        ct = torch.empty(nq, dtype=torch.int32, device=queries.device)
+        self.index.search_async(queries, k, ids, sc, ct, stream=torch.cuda.current_stream().cuda_stream)
+        return ids, sc, ct
+
+    @staticmethod
+    def _hip_merge(g_ids, g_sc, g_ct):
+        _, nq, k = g_ids.shape
+        ids = torch.empty(nq, k, dtype=torch.int64, device=g_ids.device)
+        sc = torch.empty(nq, k, dtype=torch.float32, device=g_ids.device)
+        ct = torch.empty(nq, dtype=torch.int32, device=g_ids.device)
+        merge_topk(g_ids, g_sc, g_ct, ids, sc, ct, stream=torch.cuda.current_stream().cuda_stream)
+        return ids, sc, ct
+
+    def search(self, queries: torch.Tensor, k: int):
+        ids, sc, ct = self._local(queries, k)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            return ids, sc, ct
+        nq, k = ids.shape
+        # concatenated layout (dim 0 = rank-major): the form both NCCL/RCCL and gloo accept
+        g_ids = torch.empty((world * nq, k), dtype=ids.dtype, device=ids.device)
+        g_sc = torch.empty((world * nq, k), dtype=sc.dtype, device=sc.device)
+        g_ct = torch.empty((world * nq,), dtype=ct.dtype, device=ct.device)
+        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_sc, sc.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_ct, ct.contiguous(), group=self.group)
+        return self._merge(g_ids.view(world, nq, k), g_sc.view(world, nq, k), g_ct.view(world, nq))

@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's dense-path Python (embeddings / embedding_pipeline /
+retrieve helpers) against values captured from the reference itself
+(tests/golden/reference_host_logic.json, made by tests/golden/make_goldens.py) and against the
+behaviours the reference's own unit tests assert (tests/unit/test_embeddings_client.py,
+test_embedding_pipeline.py, test_retrieve_planner.py)."""
+import json
+import struct
+from datetime import datetime, timezone
+from pathlib import Path
+from uuid import UUID, uuid4
+
+import pytest
+
+from cadence_rag_amd import embedding_pipeline, embeddings
+from cadence_rag_amd import retrieve as rt
+from cadence_rag_amd.config import Settings, settings
+from cadence_rag_amd.embeddings import EmbeddingClientError, EmbeddingResult
+
+GOLD = json.loads((Path(__file__).resolve().parent / "golden" / "reference_host_logic.json").read_text())
+
+
+# ---- settings ---------------------------------------------------------------------------------
+def test_settings_defaults_match_reference_config():
+    s = Settings()
+    assert (s.embeddings_base_url, s.embeddings_model_id, s.embeddings_dim) == ("", "Qwen/Qwen3-Embedding-4B", 1024)
+    assert (s.embeddings_timeout_s, s.embeddings_batch_size) == (180.0, 32)
+    assert (s.embeddings_exact_scan_threshold, s.embeddings_hnsw_ef_search) == (2000, 80)
+    assert s.ingest_auto_embed_on_success is True and s.ingest_auto_embed_fail_on_error is False
+
+
+def test_settings_env_is_case_insensitive(monkeypatch):
+    monkeypatch.setenv("embeddings_dim", "256")
+    monkeypatch.setenv("EMBEDDINGS_BASE_URL", "native")
+    s = Settings.from_env()
+    assert s.embeddings_dim == 256 and s.embeddings_base_url == "native"
+
+
+# ---- S1 vector literal --------------------------------------------------------------------------
+def test_vector_literal_matches_reference_and_roundtrips_f32():
+    for case in GOLD["vector_literal"]:
+        vals = [struct.unpack("<f", bytes.fromhex(h))[0] for h in case["values_f32_hex"]]
+        lit = rt._vector_literal(vals)
+        assert lit == case["literal"]
+        assert embedding_pipeline._vector_literal(vals) == case["literal"]
+        back = rt._parse_vector(lit)
+        assert [struct.pack("<f", float(v)).hex() for v in back] == [h if h != "00000080" else "00000080"
+                                                                    for h in case["values_f32_hex"]]
+
+
+# ---- S2 planner -----------------------------------------------------------------------------------
+def _scope(label):
+    call = UUID("11111111-2222-3333-4444-555555555555")
+    now = datetime(2026, 1, 2, 3, 4, 5, tzinfo=timezone.utc)
+    return {
+        "none": (None, None),
+        "empty_filters": (rt.RetrieveFilters(), None),
+        "call_ids": (rt.RetrieveFilters(call_ids=[call]), [call]),
+        "resolved_empty": (rt.RetrieveFilters(external_id="x"), []),
+        "dates": (rt.RetrieveFilters(date_from=now, date_to=now), None),
+        "tags": (rt.RetrieveFilters(call_tags=["a"]), None),
+    }[label]
+
+
+def test_choose_dense_mode_truth_table(monkeypatch):
+    for row in GOLD["choose_dense_mode"]:
+        monkeypatch.setattr(settings, "embeddings_exact_scan_threshold", row["threshold"])
+        filters, call_ids = _scope(row["scope"])
+        assert rt._choose_dense_mode(row["rows"], filters, call_ids) == row["mode"], row
+        assert rt._dense_has_scoping(filters, call_ids) == row["has_scoping"], row
+
+
+def test_choose_dense_mode_reference_unit_cases(monkeypatch):
+    # /root/reference/tests/unit/test_retrieve_planner.py, same four cases
+    monkeypatch.setattr(settings, "embeddings_exact_scan_threshold", 2000)
+    f = rt.RetrieveFilters(call_ids=[uuid4()])
+    assert rt._choose_dense_mode(estimated_rows=200, filters=f, call_ids=f.call_ids) == "exact"
+    f = rt.RetrieveFilters(date_from=datetime.now(timezone.utc), date_to=datetime.now(timezone.utc))
+    assert rt._choose_dense_mode(estimated_rows=5000, filters=f, call_ids=None) == "ann"
+    monkeypatch.setattr(settings, "embeddings_exact_scan_threshold", 5000)
+    assert rt._choose_dense_mode(estimated_rows=100, filters=None, call_ids=None) == "ann"
+    monkeypatch.setattr(settings, "embeddings_exact_scan_threshold", 10)
+    assert rt._choose_dense_mode(estimated_rows=0, filters=None, call_ids=None) == "exact"
+
+
+# ---- S8 RRF ---------------------------------------------------------------------------------------
+def test_rrf_merge_matches_reference():
+    for case in GOLD["rrf_merge"]:
+        lanes = {lane: [{"chunk_id": i, "tag": f"r{i}"} for i in ids] for lane, ids in case["lanes"]}
+        merged = rt._rrf_merge(lanes, "chunk_id")
+        assert [m[0]["chunk_id"] for m in merged] == case["order"]
+        assert [sorted(m[1]) for m in merged] == case["hits"]
+        assert [m[2] for m in merged] == case["scores"]  # same float operations, bit-identical
+
+
+# ---- B1/B2 adaptive batching ------------------------------------------------------------------------
+def test_infer_batch_size_limit_matches_reference():
+    for case in GOLD["infer_batch_size_limit"]:
+        assert embedding_pipeline.infer_batch_size_limit(case["message"]) == case["limit"], case
+
+
+def test_embed_texts_adaptive_call_traces(monkeypatch):
+    for case in GOLD["embed_texts_adaptive"]:
+        calls = []
+
+        def fake(texts, _c=case, _calls=calls):
+            _calls.append(len(texts))
+            if len(texts) > _c["limit"]:
+                raise EmbeddingClientError(
+                    f"inference request batch-size must be <= {_c['limit']}" if _c["hint"] else "backend busy")
+            return EmbeddingResult(vectors=[[0.0] * 4 for _ in texts], model="m")
+
+        monkeypatch.setattr(embedding_pipeline, "embed_texts", fake)
+        res = embedding_pipeline._embed_texts_adaptive([f"t{i}" for i in range(case["n_texts"])],
+                                                       batch_size=case["batch_size"])
+        assert calls == case["calls"], case
+        assert len(res.vectors) == case["n_vectors"] and res.model == case["model"]
+
+
+def test_embed_texts_adaptive_single_row_failure_reraises(monkeypatch):
+    def boom(texts):
+        raise EmbeddingClientError("upstream unavailable")
+
+    monkeypatch.setattr(embedding_pipeline, "embed_texts", boom)
+    with pytest.raises(EmbeddingClientError):
+        embedding_pipeline._embed_texts_adaptive(["only-one"], batch_size=4)
+
+
+# ---- C1..C6 client ----------------------------------------------------------------------------------
+class _FakeEncoder:
+    def __init__(self, dim, model="fake-native"):
+        self.dim, self.model, self.calls = dim, model, []
+
+    def encode(self, texts):
+        self.calls.append(list(texts))
+        return [[float(len(t))] + [0.0] * (self.dim - 1) for t in texts], self.model
+
+
+def test_client_error_strings_match_reference(monkeypatch):
+    want = GOLD["client_errors"]
+    monkeypatch.setattr(settings, "embeddings_base_url", "")
+    with pytest.raises(EmbeddingClientError) as e:
+        embeddings.embed_texts(["hello"])
+    assert str(e.value) == want["not_configured"]["message"]
+    with pytest.raises(EmbeddingClientError) as e:
+        embeddings._validate_texts(["", "  ", None])
+    assert str(e.value) == want["no_texts"]["message"]
+    monkeypatch.setattr(settings, "embeddings_dim", 4)
+    with pytest.raises(EmbeddingClientError) as e:
+        embeddings._validate_vectors([[0.1, 0.2, 0.3, 0.4], [0.1, 0.2]])
+    assert str(e.value) == want["bad_dim"]["message"]
+    with pytest.raises(EmbeddingClientError) as e:
+        embeddings.embed_texts_batched(["a"], batch_size=-1)
+    assert str(e.value) == want["batch_zero"]["message"]
+    assert embeddings._validate_texts(["  a ", "", "b", 3, None, " c"]) == want["validate_texts_keeps"]
+
+
+class _Resp:
+    def __init__(self, status, body):
+        self.status_code, self._body, self.text = status, body, str(body)
+
+    def json(self):
+        return self._body
+
+
+class _Client:
+    def __init__(self, resp, log):
+        self._resp, self._log = resp, log
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return None
+
+    def post(self, url, json):
+        self._log.append({"url": url, "payload": json})
+        return self._resp(json) if callable(self._resp) else self._resp
+
+
+def test_http_gateway_path_speaks_the_reference_protocol(monkeypatch):
+    import httpx
+    want = GOLD["client_errors"]
+    log = []
+    monkeypatch.setattr(settings, "embeddings_base_url", "http://embed.local/")
+    monkeypatch.setattr(settings, "embeddings_dim", 2)
+    for name, resp in (("http_500", _Resp(500, {"detail": "x" * 500})),
+                       ("missing_list", _Resp(200, {"model": "m"})),
+                       ("count_mismatch", _Resp(200, {"embeddings": [[1.0, 2.0]], "model": "m"}))):
+        monkeypatch.setattr(httpx, "Client", lambda *a, _r=resp, **k: _Client(_r, log))
+        with pytest.raises(EmbeddingClientError) as e:
+            embeddings.embed_texts(["a", "b"])
+        assert str(e.value) == want[name]["message"], name
+    assert log[0]["url"] == "http://embed.local/embed"
+    assert log[0]["payload"] == {"texts": ["a", "b"], "model": settings.embeddings_model_id}
+
+
+def test_embed_texts_batched_splits_requests(monkeypatch):
+    # /root/reference/tests/unit/test_embeddings_client.py::test_embed_texts_batched_splits_requests
+    enc = _FakeEncoder(3)
+    monkeypatch.setattr(settings, "embeddings_base_url", "native")
+    monkeypatch.setattr(settings, "embeddings_dim", 3)
+    embeddings.set_encoder(enc)
+    try:
+        res = embeddings.embed_texts_batched(["a", "b", "c", "d", "e"], batch_size=2)
+    finally:
+        embeddings.set_encoder(None)
+    assert [len(c) for c in enc.calls] == [2, 2, 1]
+    assert len(res.vectors) == 5 and res.model == "fake-native"
+
+
+def test_native_backend_validates_dim_and_wraps_errors(monkeypatch):
+    monkeypatch.setattr(settings, "embeddings_base_url", "native://qwen3")
+    monkeypatch.setattr(settings, "embeddings_dim", 4)
+    with pytest.raises(EmbeddingClientError, match="not loaded"):
+        embeddings.embed_texts(["x"])
+    embeddings.set_encoder(_FakeEncoder(3))
+    try:
+        with pytest.raises(EmbeddingClientError, match="embedding 0 has dim 3; expected 4"):
+            embeddings.embed_texts(["x"])
+
+        class Boom:
+            def encode(self, texts):
+                raise MemoryError("HIP out of memory")
+
+        embeddings.set_encoder(Boom())
+        with pytest.raises(EmbeddingClientError, match="native embedding encoder failed"):
+            embeddings.embed_texts(["x"])
+    finally:
+        embeddings.set_encoder(None)
+
+
+# ---- B6/B7 backfill ---------------------------------------------------------------------------------
+def test_backfill_guards_match_reference(monkeypatch):
+    want = GOLD["backfill_guards"]
+    monkeypatch.setattr(embedding_pipeline, "embeddings_enabled", lambda: False)
+    with pytest.raises(RuntimeError) as e:
+        embedding_pipeline.run_embedding_backfill(batch_size=8)
+    assert str(e.value) == want["disabled"]
+    monkeypatch.setattr(embedding_pipeline, "embeddings_enabled", lambda: True)
+    with pytest.raises(RuntimeError) as e:
+        embedding_pipeline.run_embedding_backfill(batch_size=0)
+    assert str(e.value) == want["batch_zero"]
+    monkeypatch.setattr(settings, "embeddings_dim", 0)
+    with pytest.raises(RuntimeError) as e:
+        embedding_pipeline.run_embedding_backfill(batch_size=8)
+    assert str(e.value) == want["dim_zero"]
+    assert [vars(s) for s in embedding_pipeline.TABLE_SPECS] == GOLD["table_specs"]
+
+
+def _tables():
+    c1, c2 = UUID(int=1), UUID(int=2)
+    return c1, c2, {
+        "chunks": {
+            3: {"call_id": c1, "text": "third", "embedding": None},
+            1: {"call_id": c1, "text": "first", "embedding": None},
+            2: {"call_id": c2, "text": "   ", "embedding": None},      # blank: never fetched
+            4: {"call_id": c2, "text": "done", "embedding": [1.0, 0.0]},  # already embedded
+            5: {"call_id": c2, "text": "fifth", "embedding": None},
+        },
+        "artifact_chunks": {7: {"call_id": c2, "text": "artifact", "embedding": None}},
+    }
+
+
+def test_run_embedding_backfill_end_to_end(monkeypatch, capsys):
+    c1, c2, tables = _tables()
+    store = embedding_pipeline.InMemoryStore(tables)
+    enc = _FakeEncoder(2)
+    monkeypatch.setattr(settings, "embeddings_base_url", "native")
+    monkeypatch.setattr(settings, "embeddings_dim", 2)
+    monkeypatch.setattr(settings, "embeddings_batch_size", 2)
+    embeddings.set_encoder(enc)
+    embedding_pipeline.set_store(store)
+    try:
+        summary = embedding_pipeline.run_embedding_backfill(batch_size=2, source="embed_backfill")
+        assert summary.rows_updated == 4 and summary.per_table == {"chunks": 3, "artifact_chunks": 1}
+        assert summary.calls_touched == 2 and summary.ingestion_runs_inserted == 2
+        assert summary.model_used == "fake-native"
+        assert enc.calls == [["first", "third"], ["fifth"], ["artifact"]]  # ORDER BY id, LIMIT batch
+        assert tables["chunks"][2]["embedding"] is None and tables["chunks"][4]["embedding"] == [1.0, 0.0]
+        cfg = json.loads(store.runs[0]["embedding_config"])
+        assert cfg["enabled"] is True and cfg["dim"] == 2 and cfg["source"] == "embed_backfill"
+        assert [r["call_id"] for r in store.runs] == sorted([c1, c2], key=str)
+        # resumable: nothing left, second run is a no-op apart from the (empty) audit
+        again = embedding_pipeline.run_embedding_backfill(batch_size=2)
+        assert again.rows_updated == 0 and again.ingestion_runs_inserted == 0
+        # per-call scope (ingest auto-embed path, ingest_fs.py:816)
+        tables["chunks"][9] = {"call_id": c1, "text": "late", "embedding": None}
+        tables["chunks"][10] = {"call_id": c2, "text": "other call", "embedding": None}
+        scoped = embedding_pipeline.run_embedding_backfill(batch_size=8, call_id=c1, source="ingest_auto_embed")
+        assert scoped.rows_updated == 1 and tables["chunks"][10]["embedding"] is None
+
+        from cadence_rag_amd.scripts import embed_backfill
+        embed_backfill.main()
+        out = capsys.readouterr().out.strip().splitlines()
+        assert out[0] == "[embed_backfill] finished table=chunks updated=1"
+        assert out[1] == "[embed_backfill] finished table=artifact_chunks updated=0"
+        # model = the LAST table's model; an idle last table reports the configured id (the
+        # reference's loop does the same: embedding_pipeline.py:259-268)
+        assert out[2] == ("[embed_backfill] complete rows_updated=1 calls_touched=1 "
+                          f"ingestion_runs_inserted=1 model={settings.embeddings_model_id}")
+    finally:
+        embeddings.set_encoder(None)
+        embedding_pipeline.set_store(None)
+
+
+def test_update_embeddings_rejects_length_mismatch():
+    embedding_pipeline.set_store(embedding_pipeline.InMemoryStore({"chunks": {}}))
+    try:
+        with pytest.raises(RuntimeError, match="row/vector mismatch for chunks: 1 rows vs 0 vectors"):
+            embedding_pipeline._update_embeddings(
+                embedding_pipeline.TABLE_SPECS[0],
+                [embedding_pipeline.PendingRow(1, UUID(int=1), "x")], [])
+    finally:
+        embedding_pipeline.set_store(None)

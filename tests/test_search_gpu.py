@@ -1,0 +1,283 @@
+"""Parity of the HIP dense-search path against the CPU oracle and the committed golden fixtures,
+through the C ABI (DenseIndex -> libcrag_dense.so).  Bar (BASELINE.json): identical top-k id order,
+|dscore| <= 1e-4 vs the fp64 exact scan, recall@10 = 1.0."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from cadence_rag_amd import retrieve as rt
+from cadence_rag_amd.dense_index import DenseIndex, merge_topk
+from tests.helpers import assert_topk_matches, cpu_merge_topk, unit_rows
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+TOL = 1e-4  # BASELINE.json: cosine scores within 1e-4 (fp32)
+
+
+def _check(corpus, queries, k, *, mask=None, ids=None, index=None):
+    ix = index or DenseIndex(corpus.shape[1], capacity=max(len(corpus), 1))
+    try:
+        if index is None and len(corpus):
+            ix.add(corpus, ids=ids)
+        packed = None if mask is None else DenseIndex.pack_mask(mask)
+        got = ix.search(queries, k, row_mask=packed)
+        omask = None if mask is None else np.packbits(mask, axis=-1, bitorder="little")
+        want = oracle.exact_topk(queries, corpus, k, ids=ids, mask=omask, mode=oracle.F64)
+        assert_topk_matches(*got, *want, tol=TOL)
+        return got
+    finally:
+        if index is None:
+            ix.close()
+
+
+def test_golden_4096(gpu):
+    g = np.load(GOLD / "dense_scan_4096.npz")
+    rng = np.random.default_rng(int(g["seed"]))
+    a = rng.standard_normal((int(g["n"]), 1024))
+    corpus = (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    with DenseIndex(1024, capacity=4096) as ix:
+        ix.add(corpus)
+        ids, scores, counts = ix.search(g["queries"], int(g["k"]))
+    assert np.array_equal(ids, g["ids"].astype(np.int64))  # bit-exact order on the pinned fixture
+    assert np.max(np.abs(scores - g["scores"])) <= TOL
+    assert np.all(counts == int(g["k"]))
+
+
+def test_golden_edge_cases(gpu):
+    g = np.load(GOLD / "dense_scan_257_edge.npz")
+    k = int(g["k"])
+    with DenseIndex(1024, capacity=257) as ix:
+        ix.add(g["corpus"])
+        ids, scores, counts = ix.search(g["queries"], k)
+        assert np.array_equal(ids, g["ids"].astype(np.int64))  # ties by ascending id, NaN/zero rows absent
+        assert np.array_equal(counts, g["counts"])
+        assert np.max(np.abs(scores - g["scores"])) <= TOL
+        ids, scores, counts = ix.search(g["queries"], k, row_mask=DenseIndex.pack_mask(g["mask"]))
+        assert np.array_equal(ids, g["masked_ids"].astype(np.int64))
+        assert np.array_equal(counts, g["masked_counts"])
+        assert ix.count_eligible() == 257 - 2  # zero row + NaN row
+        assert ix.count_eligible(DenseIndex.pack_mask(g["mask"][0])) == int(
+            (g["mask"][0] & ~np.isin(np.arange(257), [5, 100])).sum())
+
+
+@pytest.mark.parametrize("n,nq,k", [
+    (1, 1, 1), (7, 2, 10), (31, 2, 10), (32, 3, 32), (33, 1, 5), (257, 1, 5), (1000, 3, 10),
+    (4096, 32, 10), (5000, 33, 33), (20000, 33, 50), (9999, 5, 64), (30000, 64, 100), (12345, 7, 128),
+])
+def test_random_corpora_match_oracle(gpu, n, nq, k):
+    rng = np.random.default_rng(n * 7919 + nq * 31 + k)
+    _check(unit_rows(rng, n), rng.standard_normal((nq, 1024)).astype(np.float32), k)
+
+
+def test_unnormalised_rows_and_queries(gpu):
+    rng = np.random.default_rng(99)
+    corpus = (rng.standard_normal((3000, 1024)) * rng.uniform(0.01, 50, (3000, 1))).astype(np.float32)
+    q = (rng.standard_normal((4, 1024)) * 1e3).astype(np.float32)
+    _check(corpus, q, 20)
+
+
+@pytest.mark.parametrize("frac,per_query", [(0.5, False), (0.1, True), (0.001, True), (0.0, False), (1.0, True)])
+def test_row_masks(gpu, frac, per_query):
+    rng = np.random.default_rng(int(frac * 1000) + per_query)
+    corpus = unit_rows(rng, 5000)
+    q = rng.standard_normal((8, 1024)).astype(np.float32)
+    mask = rng.random((8, 5000) if per_query else (5000,)) < frac
+    _check(corpus, q, 10, mask=mask)
+
+
+def test_exact_ties_break_by_ascending_position(gpu):
+    rng = np.random.default_rng(3)
+    corpus = unit_rows(rng, 3000)
+    corpus[1500] = corpus[3]
+    corpus[2999] = corpus[3]
+    corpus[10:20] = corpus[10]  # ten identical rows
+    q = np.stack([corpus[3] * 2.0, corpus[10], rng.standard_normal(1024).astype(np.float32)])
+    ids, scores, counts = _check(corpus, q, 20)
+    assert list(ids[0, :3]) == [3, 1500, 2999]
+    assert list(ids[1, :10]) == list(range(10, 20))
+
+
+def test_zero_nan_inf_rows_and_bad_queries(gpu):
+    rng = np.random.default_rng(4)
+    corpus = unit_rows(rng, 1000)
+    corpus[0] = 0.0
+    corpus[1, 5] = np.nan
+    corpus[2, 7] = np.inf
+    q = rng.standard_normal((3, 1024)).astype(np.float32)
+    q[1] = 0.0        # zero query: pgvector gives NaN distances -> nothing eligible
+    q[2, 0] = np.nan  # NaN query
+    ids, scores, counts = _check(corpus, q, 10)
+    assert counts.tolist() == [10, 0, 0]
+    assert not np.isin(ids[0], [0, 1, 2]).any()
+
+
+def test_small_dims_are_zero_padded(gpu):
+    for dim in (4, 100, 256, 1000):
+        rng = np.random.default_rng(dim)
+        corpus = rng.standard_normal((777, dim)).astype(np.float32)
+        q = rng.standard_normal((5, dim)).astype(np.float32)
+        _check(corpus, q, 10)
+
+
+def test_external_ids_incremental_add_update_and_roundtrip(gpu):
+    rng = np.random.default_rng(8)
+    a, b = unit_rows(rng, 1000), unit_rows(rng, 777)
+    ids_a = np.arange(10_000, 11_000, dtype=np.int64)
+    ids_b = np.arange(50_000_000_000, 50_000_000_777, dtype=np.int64)  # > 2^32: ids are 64-bit
+    q = rng.standard_normal((4, 1024)).astype(np.float32)
+    with DenseIndex(1024, capacity=2000) as ix:
+        ix.add(a, ids=ids_a)
+        ix.add(b, ids=ids_b)
+        assert len(ix) == 1777
+        both, ids = np.concatenate([a, b]), np.concatenate([ids_a, ids_b])
+        _check(both, q, 25, ids=ids, index=ix)
+        rows, got_ids = ix.get_rows(990, 20)  # straddles the two adds and a 32-row tile boundary
+        assert np.array_equal(rows, both[990:1010]) and np.array_equal(got_ids, ids[990:1010])
+        fresh = unit_rows(rng, 5)
+        ix.update(998, fresh)  # re-embed in place
+        both[998:1003] = fresh
+        _check(both, q, 25, ids=ids, index=ix)
+        with pytest.raises(Exception, match="capacity exceeded"):
+            ix.add(unit_rows(rng, 300))
+
+
+def test_device_pointers_and_async_entry(gpu):
+    import torch
+    rng = np.random.default_rng(12)
+    corpus, q = unit_rows(rng, 6000), rng.standard_normal((9, 1024)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    with DenseIndex(1024, capacity=6000) as ix:
+        ix.add(torch.from_numpy(corpus).to(dev))
+        dq = torch.from_numpy(q).to(dev)
+        oi = torch.empty(9, 10, dtype=torch.int64, device=dev)
+        osc = torch.empty(9, 10, dtype=torch.float32, device=dev)
+        oc = torch.empty(9, dtype=torch.int32, device=dev)
+        for _ in range(3):  # consecutive passes alternate scan direction; results must not change
+            ix.search_async(dq, 10, oi, osc, oc, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want = oracle.exact_topk(q, corpus, 10, mode=oracle.F64)
+            assert_topk_matches(oi.cpu().numpy(), osc.cpu().numpy(), oc.cpu().numpy(), *want, tol=TOL)
+
+
+def test_argument_validation_through_the_abi(gpu):
+    rng = np.random.default_rng(1)
+    with DenseIndex(1024, capacity=100) as ix:
+        ix.add(unit_rows(rng, 100))
+        q = rng.standard_normal((1, 1024)).astype(np.float32)
+        for bad_k in (0, 129, -3):
+            with pytest.raises(Exception, match="k must be in"):
+                ix.search(q, bad_k)
+        with pytest.raises(ValueError):
+            ix.search(rng.standard_normal((1, 512)).astype(np.float32), 5)
+
+
+def test_merge_topk_kernel_matches_cpu_merge(gpu):
+    import torch
+    rng = np.random.default_rng(21)
+    r, nq, k = 8, 13, 10
+    sc = np.sort(rng.standard_normal((r, nq, k)).astype(np.float32), axis=-1)[..., ::-1].copy()
+    sc[3, :, 2] = sc[0, :, 1]  # cross-shard exact ties: lower id must win
+    ids = rng.permutation(r * nq * k).reshape(r, nq, k).astype(np.int64)
+    ct = rng.integers(0, k + 1, size=(r, nq)).astype(np.int32)
+    ct[:, 0] = 0  # a query with no eligible row anywhere
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(x).to(dev) for x in (ids, sc, ct)]
+    oi = torch.empty(nq, k, dtype=torch.int64, device=dev)
+    osc = torch.empty(nq, k, dtype=torch.float32, device=dev)
+    oc = torch.empty(nq, dtype=torch.int32, device=dev)
+    merge_topk(*t, oi, osc, oc)
+    torch.cuda.synchronize()
+    wi, ws, wc = cpu_merge_topk(*[torch.from_numpy(x) for x in (ids, sc, ct)])
+    assert torch.equal(oc.cpu(), wc)
+    assert torch.equal(oi.cpu(), wi)
+    assert torch.equal(osc.cpu().nan_to_num(nan=7.0), ws.nan_to_num(nan=7.0))
+
+
+def test_sharded_equals_unsharded(gpu):
+    """Two shards on one GPU + the merge kernel == one index over the whole corpus."""
+    import torch
+    rng = np.random.default_rng(33)
+    corpus, q = unit_rows(rng, 9000), rng.standard_normal((6, 1024)).astype(np.float32)
+    k, dev = 10, torch.device("cuda", 0)
+    parts = []
+    for lo, hi in ((0, 4500), (4500, 9000)):
+        with DenseIndex(1024, capacity=4500) as ix:
+            ix.add(corpus[lo:hi], ids=np.arange(lo, hi))
+            parts.append(ix.search(q, k))
+    g = [torch.from_numpy(np.stack([p[i] for p in parts])).to(dev) for i in range(3)]
+    oi = torch.empty(6, k, dtype=torch.int64, device=dev)
+    osc = torch.empty(6, k, dtype=torch.float32, device=dev)
+    oc = torch.empty(6, dtype=torch.int32, device=dev)
+    merge_topk(*g, oi, osc, oc)
+    torch.cuda.synchronize()
+    want = oracle.exact_topk(q, corpus, k, mode=oracle.F64)
+    assert_topk_matches(oi.cpu().numpy(), osc.cpu().numpy(), oc.cpu().numpy(), *want, tol=TOL)
+
+
+def test_full_size_properties_100k(gpu):
+    """BASELINE configs[1] size: properties that need no full oracle pass — planted neighbours are
+    found, scores sorted, repeatable, and a sampled oracle check gives recall@10 = 1.0."""
+    import torch
+    g = torch.Generator().manual_seed(1234)
+    c = torch.randn(100_000, 1024, generator=g)
+    c /= c.norm(dim=1, keepdim=True)
+    corpus = c.numpy()
+    rng = np.random.default_rng(4321)
+    planted_rows = rng.choice(100_000, size=32, replace=False)
+    q = corpus[planted_rows] + 0.05 * rng.standard_normal((32, 1024)).astype(np.float32) / 32.0
+    with DenseIndex(1024, capacity=100_000) as ix:
+        ix.add(corpus)
+        ids, scores, counts = ix.search(q, 10)
+        ids2, scores2, _ = ix.search(q, 10)  # the reversed pass
+        assert np.array_equal(ids, ids2) and np.array_equal(scores, scores2)
+        assert np.array_equal(ids[:, 0], planted_rows)
+        assert np.all(np.diff(scores, axis=1) <= 0) and np.all(counts == 10)
+        big_ids, big_scores, _ = ix.search(q, 100)
+        assert np.array_equal(big_ids[:, :10], ids)  # top-10 is a prefix of top-100 (two kernels)
+        want = oracle.exact_topk(q[:8], corpus, 10, mode=oracle.F64, fast=True)
+        assert_topk_matches(ids[:8], scores[:8], counts[:8], *want, tol=TOL)
+        recall = np.mean([len(set(ids[i]) & set(want[0][i])) / 10 for i in range(8)])
+        assert recall == 1.0
+
+
+def test_dense_table_lane_rows_and_filters(gpu):
+    """_fetch_chunks_dense / _fetch_artifacts_dense row shapes and filter semantics."""
+    from datetime import datetime, timedelta, timezone
+    from uuid import UUID
+    rng = np.random.default_rng(5)
+    n = 400
+    vecs = unit_rows(rng, n)
+    calls = [UUID(int=i % 4 + 1) for i in range(n)]
+    t0 = datetime(2026, 1, 1, tzinfo=timezone.utc)
+    started = [(t0 + timedelta(days=i % 4)).replace(tzinfo=None) for i in range(n)]
+    table = rt.DenseTable("chunks", "chunk_id", dim=1024, capacity=n)
+    try:
+        table.add(vecs, {"chunk_id": list(range(100, 100 + n)), "call_id": calls,
+                         "speaker": ["S"] * n, "start_ts_ms": list(range(n)), "end_ts_ms": list(range(1, n + 1)),
+                         "text": [f"chunk {i}" for i in range(n)]},
+                  call_started_at=started,
+                  call_tags={UUID(int=1): ["alpha"], UUID(int=2): ["beta"], UUID(int=3): [], UUID(int=4): ["alpha", "x"]})
+        q = vecs[7] * 3.0
+        rows = rt._fetch_chunks_dense(table, rt._vector_literal(q.tolist()), None, None, "exact", 5)
+        assert list(rows[0]) == ["chunk_id", "call_id", "speaker", "start_ts_ms", "end_ts_ms", "text", "score"]
+        assert rows[0]["chunk_id"] == 107 and rows[0]["text"] == "chunk 7" and rows[0]["score"] == pytest.approx(1.0, abs=1e-6)
+        assert [r["score"] for r in rows] == sorted((r["score"] for r in rows), reverse=True)
+        # call_ids scope
+        f = rt.RetrieveFilters(call_ids=[UUID(int=2)])
+        rows = rt._fetch_chunks_dense(table, q, f, f.call_ids, "exact", 50)
+        assert len(rows) == 50 and all(r["call_id"] == UUID(int=2) for r in rows)
+        assert rt._estimate_dense_candidates(table, "chunks", f, f.call_ids) == 100
+        # date range + tags
+        f = rt.RetrieveFilters(date_from=t0 + timedelta(days=1), date_to=t0 + timedelta(days=2), call_tags=["beta"])
+        rows = rt._fetch_chunks_dense(table, q, f, None, "ann", 1000)
+        assert len(rows) == 100 and {r["call_id"] for r in rows} == {UUID(int=2)}
+        want = oracle.exact_topk(q[None], vecs, 128, mask=np.packbits(np.array([c == UUID(int=2) for c in calls]),
+                                                                       bitorder="little"), mode=oracle.F64)
+        assert [r["chunk_id"] - 100 for r in rows] == want[0][0, :100].tolist()
+        # empty scope -> no rows, planner says exact
+        assert rt._fetch_chunks_dense(table, q, rt.RetrieveFilters(external_id="zz"), [], "exact", 10) == []
+        assert rt._estimate_dense_candidates(table, "chunks", rt.RetrieveFilters(external_id="zz"), []) == 0
+    finally:
+        table.close()
