@@ -40,6 +40,15 @@ SIGNATURES = {
                                            _c.POINTER(_c.c_double)]),
     "crag_index_scan_geometry": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int),
                                             _c.POINTER(_c.c_int), _c.POINTER(_c.c_int64)]),
+    # include/crag_encoder.h
+    "crag_enc_embed_gather": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int64, _P]),
+    "crag_enc_rmsnorm": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_float, _P]),
+    "crag_enc_qk_norm_rope": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_float, _P]),
+    "crag_enc_v_transpose": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _P]),
+    "crag_enc_attention": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int64, _c.c_int, _c.c_int,
+                                      _c.c_float, _P]),
+    "crag_enc_swiglu": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int, _P]),
+    "crag_enc_pool_normalize": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
 }
 
 

@@ -220,6 +220,9 @@ extern "C" {
 
 const char *crag_last_error(void) { return g_err; }
 
+// used by the other translation units of the library (crag_encoder.hip) to report errors
+void crag_set_error_(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
 const char *crag_version(void) { return "cadence-rag_amd dense lane 0.1 (gfx950)"; }
 
 int crag_device_count(void) {

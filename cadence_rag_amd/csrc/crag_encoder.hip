@@ -1,0 +1,500 @@
+// crag_encoder.hip — hand-written HIP operators of the Qwen3-Embedding encoder lane for gfx950.
+// C ABI: include/crag_encoder.h.  Everything of the decoder forward except the plain linear layers
+// (library GEMMs issued by the Python host) lives here: embedding gather, RMSNorm (+ residual),
+// per-head q/k RMSNorm + RoPE, V transpose, causal GQA flash attention (bf16 MFMA), SwiGLU, and the
+// gateway's pooling / slice / L2 normalisation.
+//
+// Reference math (not code): P620_TRITON_QWEN3_4B_EMBEDDING_RUNBOOK.md:683-716 for the
+// post-processing; the model family's public architecture for the layer (checked against
+// transformers' Qwen3Model in tests/test_encoder_gpu.py).
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/crag_encoder.h"
+
+extern "C" const char *crag_last_error(void);
+extern "C" void crag_set_error_(const char *msg);  // defined in crag_api.hip
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t u16;
+
+int efail(const char *fmt, ...) {
+    char buf[384];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    crag_set_error_(buf);
+    return -1;
+}
+
+int hip_ok(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s launch failed: %s", what, hipGetErrorString(e));
+        crag_set_error_(buf);
+        return -2;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {  // round-to-nearest-even, NaN stays NaN (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(u16, (__bf16)f);
+}
+
+struct alignas(16) Pack8 {
+    u16 v[8];
+};
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int32_t *ids, const u16 *table, u16 *out,
+                                                           int64_t n_tokens, int hidden, int64_t vocab) {
+    const int chunks = hidden >> 3;
+    for (int64_t t = blockIdx.x; t < n_tokens; t += gridDim.x) {
+        int64_t id = ids[t];
+        if (id < 0) id = 0;
+        if (id >= vocab) id = vocab - 1;
+        const Pack8 *src = reinterpret_cast<const Pack8 *>(table + id * hidden);
+        Pack8 *dst = reinterpret_cast<Pack8 *>(out + t * hidden);
+        for (int c = threadIdx.x; c < chunks; c += blockDim.x) dst[c] = src[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm (+ residual add)
+// ---------------------------------------------------------------------------------------------
+constexpr int NORM_THREADS = 256;
+constexpr int NORM_MAX_CHUNKS = 4;  // hidden <= 8 * 256 * 4 = 8192
+
+__device__ __forceinline__ float block_sum(float v, float *sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[wv] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const u16 *x, const u16 *res_in, const u16 *w,
+                                                               u16 *out, u16 *res_out, int64_t rows, int hidden,
+                                                               float eps) {
+    __shared__ float sh[NORM_THREADS / 64];
+    const int chunks = hidden >> 3;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const Pack8 *xr = reinterpret_cast<const Pack8 *>(x + r * hidden);
+        const Pack8 *rr = res_in ? reinterpret_cast<const Pack8 *>(res_in + r * hidden) : nullptr;
+        float v[NORM_MAX_CHUNKS][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+            const int c = threadIdx.x + i * NORM_THREADS;
+            if (c < chunks) {
+                const Pack8 a = xr[c];
+                Pack8 s8;
+                if (rr) {
+                    const Pack8 b = rr[c];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s8.v[e] = f2bf(bf2f(a.v[e]) + bf2f(b.v[e]));  // bf16 add, as the model does
+                } else {
+                    s8 = a;
+                }
+                if (res_out) reinterpret_cast<Pack8 *>(res_out + r * hidden)[c] = s8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[i][e] = bf2f(s8.v[e]);
+                    ss += v[i][e] * v[i][e];
+                }
+            }
+        }
+        ss = block_sum(ss, sh);
+        const float rstd = rsqrtf(ss / (float)hidden + eps);
+#pragma unroll
+        for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+            const int c = threadIdx.x + i * NORM_THREADS;
+            if (c < chunks) {
+                const Pack8 w8 = reinterpret_cast<const Pack8 *>(w)[c];
+                Pack8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.v[e] = f2bf(bf2f(w8.v[e]) * bf2f(f2bf(v[i][e] * rstd)));
+                reinterpret_cast<Pack8 *>(out + r * hidden)[c] = o;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-head q/k RMSNorm + RoPE, in place on the fused qkv rows
+// 16 lanes per head vector (8 elements each); lane j of the group pairs with lane j^8 for
+// rotate_half (element i <-> i + 64)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16 *qkv, const u16 *qw, const u16 *kw,
+                                                           const float *cos_sin, const int32_t *positions,
+                                                           int64_t n_tokens, int hq, int hkv, float eps) {
+    const int heads = hq + hkv;  // q heads then k heads are contiguous in the row
+    const int64_t row_stride = (int64_t)(hq + 2 * hkv) * CRAG_HEAD_DIM;
+    const int64_t vec = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // head-vector index
+    const int sub = threadIdx.x & 15;                                   // 8-element chunk of the head
+    if (vec >= n_tokens * heads) return;
+    const int64_t t = vec / heads;
+    const int hd = (int)(vec - t * heads);
+    u16 *p = qkv + t * row_stride + (int64_t)hd * CRAG_HEAD_DIM + sub * 8;
+    const u16 *wn = (hd < hq ? qw : kw) + sub * 8;
+    Pack8 a = *reinterpret_cast<Pack8 *>(p);
+    const Pack8 w8 = *reinterpret_cast<const Pack8 *>(wn);
+    float v[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = bf2f(a.v[e]);
+        ss += v[e] * v[e];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);  // 16-lane group
+    const float rstd = rsqrtf(ss / (float)CRAG_HEAD_DIM + eps);
+    float n[8], partner[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) n[e] = bf2f(f2bf(bf2f(w8.v[e]) * bf2f(f2bf(v[e] * rstd))));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) partner[e] = __shfl_xor(n[e], 8);
+    const int pos = positions[t];
+    const float *cs = cos_sin + ((int64_t)pos * 64 + (sub & 7) * 8) * 2;
+    const bool first_half = sub < 8;  // elements [0, 64): out = x*cos - x[i+64]*sin ; else x*cos + x[i-64]*sin
+    Pack8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float c = bf2f(f2bf(cs[2 * e])), s = bf2f(f2bf(cs[2 * e + 1]));  // the model casts cos/sin to bf16
+        const float rot = first_half ? -partner[e] : partner[e];
+        o.v[e] = f2bf(n[e] * c + rot * s);
+    }
+    *reinterpret_cast<Pack8 *>(p) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// V transpose: qkv[T, ..] V part -> Vt[hkv][128][t_pad]; one block per (32 padded slots, kv head)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void v_transpose_kernel(const u16 *qkv, u16 *vt, const int32_t *tok_of_pad,
+                                                          int64_t t_pad, int hq, int hkv) {
+    __shared__ u16 tile[32][CRAG_HEAD_DIM + 8];
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int kvh = blockIdx.y;
+    const int64_t row_stride = (int64_t)(hq + 2 * hkv) * CRAG_HEAD_DIM;
+    {
+        const int slot = threadIdx.x >> 3, c8 = threadIdx.x & 7;  // 32 slots x 8 chunks of 16 elements
+        const int32_t tok = (p0 + slot < t_pad) ? tok_of_pad[p0 + slot] : -1;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int d0 = c8 * 16 + half * 8;
+            Pack8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a.v[e] = 0;
+            if (tok >= 0)
+                a = *reinterpret_cast<const Pack8 *>(qkv + (int64_t)tok * row_stride +
+                                                     (int64_t)(hq + hkv + kvh) * CRAG_HEAD_DIM + d0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[slot][d0 + e] = a.v[e];
+        }
+    }
+    __syncthreads();
+    {
+        // each thread writes 16 slots (32 B) of one d row: 128 d rows x 2 halves = 256 threads
+        const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
+        u16 *dst = vt + ((int64_t)kvh * CRAG_HEAD_DIM + d) * t_pad + p0 + half * 16;
+        Pack8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o0.v[e] = tile[half * 16 + e][d];
+            o1.v[e] = tile[half * 16 + 8 + e][d];
+        }
+        reinterpret_cast<Pack8 *>(dst)[0] = o0;
+        reinterpret_cast<Pack8 *>(dst)[1] = o1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// causal GQA flash attention, head_dim 128, one wave = 32 query rows of one query head.
+//   S^T = K . Q^T   (A = K tile rows, B = Q^T)   -> lane holds 16 of the 32 keys of ONE query row
+//   O^T += V^T . P^T (A = V^T tile from the transposed copy, B = P^T taken straight from the S^T
+//                     accumulator registers, bf16-packed; k order as the 32x32 C/D map gives it)
+// ---------------------------------------------------------------------------------------------
+struct AttnParams {
+    const u16 *qkv;
+    const u16 *vt;
+    u16 *out;
+    const int32_t *cu, *cu_pad, *blk_seq, *blk_q0;
+    int64_t t_pad;
+    int hq, hkv;
+    float scale_log2;
+};
+
+__device__ __forceinline__ bf16x8 ld_frag(const u16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+
+__global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int group = p.hq / p.hkv;  // query heads per kv head = waves per workgroup
+    const int kvh = blockIdx.y;
+    const int head = kvh * group + wave;
+    const int seq = p.blk_seq[blockIdx.x];
+    const int q0 = p.blk_q0[blockIdx.x];
+    const int s_begin = p.cu[seq];
+    const int len = p.cu[seq + 1] - s_begin;
+    const int64_t pad_base = p.cu_pad[seq];
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t row_stride = (int64_t)(p.hq + 2 * p.hkv) * CRAG_HEAD_DIM;
+
+    // Q^T fragments (B operand): B[k = 8h + j][col c] = Q[q0 + c][16 s + 8h + j]
+    bf16x8 qf[8];
+    {
+        const u16 *qp = p.qkv + (int64_t)(s_begin + q0 + c) * row_stride + (int64_t)head * CRAG_HEAD_DIM + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = ld_frag(qp + 16 * s);
+    }
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 oacc[4] = {zero, zero, zero, zero};
+    float m = -INFINITY, l = 0.f;
+    const int n_kt = q0 / 32 + 1;
+    const u16 *kbase = p.qkv + (int64_t)s_begin * row_stride + (int64_t)(p.hq + kvh) * CRAG_HEAD_DIM + 8 * h;
+    const u16 *vbase = p.vt + (int64_t)kvh * CRAG_HEAD_DIM * p.t_pad + pad_base;
+
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int k0 = kt * 32;
+        f32x16 sacc = zero;
+        {
+            const u16 *kp = kbase + (int64_t)(k0 + c) * row_stride;  // A[row = key c][k = 8h + j]
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * s), qf[s], sacc, 0, 0, 0);
+        }
+        // lane: query row q0 + c; register i: key k0 + (i&3) + 8*(i>>2) + 4h
+        float sv[16];
+        float mloc = -INFINITY;
+        const bool diag = (kt == n_kt - 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            float v = sacc[i] * p.scale_log2;
+            if (diag && key > q0 + c) v = -INFINITY;
+            sv[i] = v;
+            mloc = fmaxf(mloc, v);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float mnew = fmaxf(m, mloc);  // finite: key k0 (<= q0 + c) is never masked
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        float lsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sv[i] = __builtin_amdgcn_exp2f(sv[i] - mnew);
+            lsum += sv[i];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l = l * alpha + lsum;
+        m = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+        // P^T fragments (B operand of k-step s2): element j = register 8*s2 + j
+        bf16x8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pf[s2][jj] = (short)f2bf(sv[8 * s2 + jj]);
+        // A operand: V^T[d = 32 dt + c][key], element j <-> key k0 + 16 s2 + 8 (j>>2) + 4h + (j&3)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const u16 *vp = vbase + (int64_t)(32 * dt + c) * p.t_pad + k0 + 4 * h;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + 16 * s2);
+                const uint2 hi = *reinterpret_cast<const uint2 *>(vp + 16 * s2 + 8);
+                const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[s2],
+                                                                   oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    // O[q0 + c][32 dt + (i&3) + 8 (i>>2) + 4h] = oacc[dt][i] / l : 4 consecutive d per register quad
+    if (q0 + c < len) {
+        const float inv = 1.f / l;
+        u16 *op = p.out + (int64_t)(s_begin + q0 + c) * ((int64_t)p.hq * CRAG_HEAD_DIM) +
+                  (int64_t)head * CRAG_HEAD_DIM + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = (uint32_t)f2bf(oacc[dt][4 * g4] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 1] * inv) << 16);
+                w.y = (uint32_t)f2bf(oacc[dt][4 * g4 + 2] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 3] * inv) << 16);
+                *reinterpret_cast<uint2 *>(op + 32 * dt + 8 * g4) = w;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SwiGLU
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_kernel(const u16 *gu, u16 *out, int64_t rows, int inter) {
+    const int chunks = inter >> 3;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i - r * chunks);
+        const Pack8 g = reinterpret_cast<const Pack8 *>(gu + r * 2 * inter)[c];
+        const Pack8 u = reinterpret_cast<const Pack8 *>(gu + r * 2 * inter + inter)[c];
+        Pack8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = bf2f(g.v[e]);
+            const float act = bf2f(f2bf(x / (1.f + __expf(-x))));  // silu in fp32, rounded to bf16 like the model
+            o.v[e] = f2bf(act * bf2f(u.v[e]));
+        }
+        reinterpret_cast<Pack8 *>(out + r * inter)[c] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooling + final norm + slice + L2 normalise (one block per sequence)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, const u16 *w, const int32_t *cu, float *out,
+                                                             int hidden, int out_dim, int mode, float eps) {
+    __shared__ float sh[4];
+    __shared__ float row[8192];
+    const int b = blockIdx.x;
+    const int t0 = cu[b], t1 = cu[b + 1];
+    if (t1 <= t0) {
+        for (int i = threadIdx.x; i < out_dim; i += blockDim.x) out[(int64_t)b * out_dim + i] = 0.f;
+        return;
+    }
+    if (mode == 0) {  // last token of the residual stream, final RMSNorm applied here
+        const u16 *x = hs + (int64_t)(t1 - 1) * hidden;
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+            const float v = bf2f(x[i]);
+            row[i] = v;
+            ss += v * v;
+        }
+        ss = block_sum(ss, sh);
+        const float rstd = rsqrtf(ss / (float)hidden + eps);
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x)
+            row[i] = bf2f(f2bf(bf2f(w[i]) * bf2f(f2bf(row[i] * rstd))));
+    } else {  // mean over the (already normed) tokens
+        const float invn = 1.f / (float)(t1 - t0);
+        for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+            float acc = 0.f;
+            for (int t = t0; t < t1; ++t) acc += bf2f(hs[(int64_t)t * hidden + i]);
+            row[i] = acc * invn;
+        }
+    }
+    __syncthreads();
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < out_dim; i += blockDim.x) ss += row[i] * row[i];
+    ss = block_sum(ss, sh);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);  // RUNBOOK:510-513 max(norm, 1e-12)
+    for (int i = threadIdx.x; i < out_dim; i += blockDim.x) out[(int64_t)b * out_dim + i] = row[i] * inv;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crag_enc_embed_gather(const int32_t *ids, const uint16_t *table, uint16_t *out, int64_t n_tokens, int hidden,
+                          int64_t vocab, void *stream) {
+    if (!ids || !table || !out) return efail("embed_gather: NULL pointer");
+    if (hidden <= 0 || (hidden & 7) || vocab <= 0 || n_tokens < 0) return efail("embed_gather: bad sizes");
+    if (n_tokens == 0) return 0;
+    const unsigned grid = (unsigned)(n_tokens < 65535 * 16 ? n_tokens : 65535 * 16);
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, table, out, n_tokens,
+                       hidden, vocab);
+    return hip_ok("embed_gather");
+}
+
+int crag_enc_rmsnorm(const uint16_t *x, const uint16_t *residual_in, const uint16_t *weight, uint16_t *out,
+                     uint16_t *residual_out, int64_t rows, int hidden, float eps, void *stream) {
+    if (!x || !weight || !out) return efail("rmsnorm: NULL pointer");
+    if (hidden <= 0 || (hidden & 7) || hidden > 8 * NORM_THREADS * NORM_MAX_CHUNKS)
+        return efail("rmsnorm: hidden must be a multiple of 8 and <= %d (got %d)", 8 * NORM_THREADS * NORM_MAX_CHUNKS, hidden);
+    if (rows <= 0) return 0;
+    const unsigned grid = (unsigned)(rows < 1048576 ? rows : 1048576);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(grid), dim3(NORM_THREADS), 0, (hipStream_t)stream, x, residual_in, weight,
+                       out, residual_out, rows, hidden, eps);
+    return hip_ok("rmsnorm");
+}
+
+int crag_enc_qk_norm_rope(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w, const float *cos_sin,
+                          const int32_t *positions, int64_t n_tokens, int hq, int hkv, float eps, void *stream) {
+    if (!qkv || !q_norm_w || !k_norm_w || !cos_sin || !positions) return efail("qk_norm_rope: NULL pointer");
+    if (hq <= 0 || hkv <= 0) return efail("qk_norm_rope: bad head counts");
+    if (n_tokens <= 0) return 0;
+    const int64_t vecs = n_tokens * (hq + hkv);
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((vecs + 15) / 16)), dim3(256), 0, (hipStream_t)stream, qkv,
+                       q_norm_w, k_norm_w, cos_sin, positions, n_tokens, hq, hkv, eps);
+    return hip_ok("qk_norm_rope");
+}
+
+int crag_enc_v_transpose(const uint16_t *qkv, uint16_t *vt, const int32_t *tok_of_pad, int64_t t_pad, int hq, int hkv,
+                         void *stream) {
+    if (!qkv || !vt || !tok_of_pad) return efail("v_transpose: NULL pointer");
+    if (t_pad <= 0 || (t_pad & 31)) return efail("v_transpose: t_pad must be a positive multiple of 32");
+    hipLaunchKernelGGL(v_transpose_kernel, dim3((unsigned)(t_pad / 32), (unsigned)hkv), dim3(256), 0,
+                       (hipStream_t)stream, qkv, vt, tok_of_pad, t_pad, hq, hkv);
+    return hip_ok("v_transpose");
+}
+
+int crag_enc_attention(const uint16_t *qkv, const uint16_t *vt, uint16_t *out, const int32_t *cu_seqlens,
+                       const int32_t *cu_pad, const int32_t *blk_seq, const int32_t *blk_q0, int n_blocks,
+                       int64_t t_pad, int hq, int hkv, float scale, void *stream) {
+    if (!qkv || !vt || !out || !cu_seqlens || !cu_pad || !blk_seq || !blk_q0) return efail("attention: NULL pointer");
+    if (hkv <= 0 || hq % hkv != 0 || hq / hkv > 8) return efail("attention: hq/hkv must be an integer <= 8");
+    if (n_blocks <= 0) return 0;
+    AttnParams p;
+    p.qkv = qkv;
+    p.vt = vt;
+    p.out = out;
+    p.cu = cu_seqlens;
+    p.cu_pad = cu_pad;
+    p.blk_seq = blk_seq;
+    p.blk_q0 = blk_q0;
+    p.t_pad = t_pad;
+    p.hq = hq;
+    p.hkv = hkv;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)n_blocks, (unsigned)hkv), dim3(64 * (hq / hkv)), 0,
+                       (hipStream_t)stream, p);
+    return hip_ok("attention");
+}
+
+int crag_enc_swiglu(const uint16_t *gate_up, uint16_t *out, int64_t rows, int inter, void *stream) {
+    if (!gate_up || !out) return efail("swiglu: NULL pointer");
+    if (inter <= 0 || (inter & 7)) return efail("swiglu: inter must be a positive multiple of 8");
+    if (rows <= 0) return 0;
+    const int64_t total = rows * (inter >> 3);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(swiglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gate_up, out, rows, inter);
+    return hip_ok("swiglu");
+}
+
+int crag_enc_pool_normalize(const uint16_t *hidden_states, const uint16_t *final_norm_w, const int32_t *cu_seqlens,
+                            float *out, int n_seqs, int hidden, int out_dim, int mode, float eps, void *stream) {
+    if (!hidden_states || !cu_seqlens || !out) return efail("pool_normalize: NULL pointer");
+    if (mode == 0 && !final_norm_w) return efail("pool_normalize: last-token mode needs the final norm weight");
+    if (hidden <= 0 || hidden > 8192 || out_dim <= 0 || out_dim > hidden) return efail("pool_normalize: bad sizes");
+    if (n_seqs <= 0) return 0;
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, hidden_states,
+                       final_norm_w, cu_seqlens, out, hidden, out_dim, mode, eps);
+    return hip_ok("pool_normalize");
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""torch-tensor wrappers over the crag_enc_* C ABI (include/crag_encoder.h).  Tensors must be
+contiguous CUDA tensors; bf16 tensors are passed as raw storage.  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import _native
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dtype}")
+
+
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _req(ids, torch.int32, "ids"); _req(table, torch.bfloat16, "table"); _req(out, torch.bfloat16, "out")
+    _native.check(_native.load().crag_enc_embed_gather(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1],
+                                                       table.shape[0], _stream()), "crag_enc_embed_gather")
+    return out
+
+
+def rmsnorm(x, weight, out, eps: float, residual_in=None, residual_out=None):
+    _req(x, torch.bfloat16, "x"); _req(weight, torch.bfloat16, "weight"); _req(out, torch.bfloat16, "out")
+    rows, hidden = x.shape
+    _native.check(_native.load().crag_enc_rmsnorm(_p(x), _p(residual_in), _p(weight), _p(out), _p(residual_out),
+                                                  rows, hidden, float(eps), _stream()), "crag_enc_rmsnorm")
+    return out
+
+
+def qk_norm_rope(qkv, q_w, k_w, cos_sin, positions, hq: int, hkv: int, eps: float):
+    _req(qkv, torch.bfloat16, "qkv"); _req(cos_sin, torch.float32, "cos_sin"); _req(positions, torch.int32, "positions")
+    _native.check(_native.load().crag_enc_qk_norm_rope(_p(qkv), _p(q_w), _p(k_w), _p(cos_sin), _p(positions),
+                                                       positions.numel(), hq, hkv, float(eps), _stream()),
+                  "crag_enc_qk_norm_rope")
+    return qkv
+
+
+def v_transpose(qkv, vt, tok_of_pad, hq: int, hkv: int):
+    _req(qkv, torch.bfloat16, "qkv"); _req(vt, torch.bfloat16, "vt"); _req(tok_of_pad, torch.int32, "tok_of_pad")
+    _native.check(_native.load().crag_enc_v_transpose(_p(qkv), _p(vt), _p(tok_of_pad), tok_of_pad.numel(), hq, hkv,
+                                                      _stream()), "crag_enc_v_transpose")
+    return vt
+
+
+def attention(qkv, vt, out, cu, cu_pad, blk_seq, blk_q0, hq: int, hkv: int, scale: float):
+    _req(qkv, torch.bfloat16, "qkv"); _req(vt, torch.bfloat16, "vt"); _req(out, torch.bfloat16, "out")
+    _native.check(_native.load().crag_enc_attention(_p(qkv), _p(vt), _p(out), _p(cu), _p(cu_pad), _p(blk_seq),
+                                                    _p(blk_q0), blk_seq.numel(), vt.shape[-1], hq, hkv, float(scale),
+                                                    _stream()), "crag_enc_attention")
+    return out
+
+
+def swiglu(gate_up, out):
+    _req(gate_up, torch.bfloat16, "gate_up"); _req(out, torch.bfloat16, "out")
+    rows, two_i = gate_up.shape
+    _native.check(_native.load().crag_enc_swiglu(_p(gate_up), _p(out), rows, two_i // 2, _stream()), "crag_enc_swiglu")
+    return out
+
+
+def pool_normalize(hidden_states, final_norm_w, cu, out, out_dim: int, mode: int, eps: float):
+    _req(hidden_states, torch.bfloat16, "hidden_states"); _req(out, torch.float32, "out")
+    _native.check(_native.load().crag_enc_pool_normalize(_p(hidden_states), _p(final_norm_w), _p(cu), _p(out),
+                                                         cu.numel() - 1, hidden_states.shape[1], out_dim, mode,
+                                                         float(eps), _stream()), "crag_enc_pool_normalize")
+    return out

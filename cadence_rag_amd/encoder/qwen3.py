@@ -1,0 +1,277 @@
+"""Qwen3-Embedding encoder on MI355X.
+
+Forward of one packed batch (T tokens of B sequences, no padding):
+  embed_gather -> 36 x [ rmsnorm(+residual) -> QKV GEMM -> q/k head-norm + RoPE (in place) ->
+  V transpose -> causal GQA flash attention -> O GEMM -> rmsnorm(+residual) -> gate|up GEMM ->
+  SwiGLU -> down GEMM ] -> last-token pool + final RMSNorm + [:out_dim] + fp32 L2 normalise.
+The GEMMs are plain library GEMMs (torch.nn.functional.linear -> hipBLASLt); every other
+operator is hand-written HIP (csrc/crag_encoder.hip).
+
+Replaces: the external gateway behind /root/reference/app/embeddings.py:53-59 whose math is
+documented in P620_TRITON_QWEN3_4B_EMBEDDING_RUNBOOK.md:683-716 (tokenise, truncate to 1024,
+forward, LAST-token pooling, slice 2560 -> 1024, L2 normalise with max(norm, 1e-12)).  Packed
+sequences mean the gateway's left-padding pooling quirk cannot occur: the pooled
+position is always the last real token.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+@dataclass
+class Qwen3Config:
+    """Architecture of Qwen/Qwen3-Embedding-4B (public model family; verify against config.json
+    when real weights are loaded)."""
+    hidden_size: int = 2560
+    num_layers: int = 36
+    num_heads: int = 32
+    num_kv_heads: int = 8
+    head_dim: int = 128
+    intermediate_size: int = 9728
+    vocab_size: int = 151665
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1_000_000.0
+    max_length: int = 1024      # gateway truncation (RUNBOOK:484,748)
+    out_dim: int = 1024         # EMBEDDINGS_DIM: slice of the 2560-d state (RUNBOOK:712-713)
+    pooling: str = "last"       # "last" (reference gateway) or "mean"
+    model_id: str = "Qwen/Qwen3-Embedding-4B"
+
+    @property
+    def q_size(self) -> int:
+        return self.num_heads * self.head_dim
+
+    @property
+    def kv_size(self) -> int:
+        return self.num_kv_heads * self.head_dim
+
+    def flops_per_token(self, avg_context: float) -> float:
+        """Forward FLOPs per token: 2 * non-embedding params + causal attention."""
+        per_layer = self.hidden_size * (self.q_size + 2 * self.kv_size) + self.q_size * self.hidden_size \
+            + 3 * self.hidden_size * self.intermediate_size
+        attn = 4.0 * (avg_context / 2.0) * self.head_dim * self.num_heads
+        return self.num_layers * (2.0 * per_layer + attn)
+
+
+@dataclass
+class PackedBatch:
+    """Device-side description of a packed batch (built once per batch on the host)."""
+    n_tokens: int
+    n_seqs: int
+    t_pad: int
+    cu: torch.Tensor          # int32 [B+1]
+    cu_pad: torch.Tensor      # int32 [B+1], 32-aligned starts in the transposed-V key axis
+    positions: torch.Tensor   # int32 [T]
+    tok_of_pad: torch.Tensor  # int32 [t_pad]
+    blk_seq: torch.Tensor     # int32 [n_blocks]
+    blk_q0: torch.Tensor      # int32 [n_blocks]
+
+    @staticmethod
+    def build(lengths: Sequence[int], device) -> "PackedBatch":
+        lens = np.asarray(lengths, dtype=np.int64)
+        if lens.size == 0 or (lens <= 0).any():
+            raise ValueError("every sequence needs at least one token")
+        cu = np.zeros(lens.size + 1, dtype=np.int64)
+        np.cumsum(lens, out=cu[1:])
+        padded = (lens + 31) // 32 * 32
+        cu_pad = np.zeros(lens.size + 1, dtype=np.int64)
+        np.cumsum(padded, out=cu_pad[1:])
+        t, t_pad = int(cu[-1]), int(cu_pad[-1])
+        seq_of_tok = np.repeat(np.arange(lens.size), lens)
+        positions = np.arange(t) - cu[seq_of_tok]
+        tok_of_pad = np.full(t_pad, -1, dtype=np.int64)
+        tok_of_pad[cu_pad[seq_of_tok] + positions] = np.arange(t)
+        nblk = padded // 32
+        blk_seq = np.repeat(np.arange(lens.size), nblk)
+        blk_q0 = (np.arange(int(nblk.sum())) - np.repeat(np.cumsum(nblk) - nblk, nblk)) * 32
+        # longest blocks first: the last q block of a long sequence walks the most key tiles
+        order = np.argsort(-blk_q0, kind="stable")
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)
+
+        return PackedBatch(t, int(lens.size), t_pad, dev(cu), dev(cu_pad), dev(positions), dev(tok_of_pad),
+                           dev(blk_seq[order]), dev(blk_q0[order]))
+
+
+class Qwen3Encoder:
+    """Weights live as bf16 CUDA tensors; `layers[i]` holds the fused projections."""
+
+    def __init__(self, config: Qwen3Config, device: Optional[torch.device] = None) -> None:
+        self.cfg = config
+        self.device = device or torch.device("cuda", 0)
+        self.embed: Optional[torch.Tensor] = None
+        self.final_norm: Optional[torch.Tensor] = None
+        self.layers: List[Dict[str, torch.Tensor]] = []
+        self.tokenizer = None
+        self._cos_sin = self._rope_table(config).to(self.device)
+
+    # -- construction -------------------------------------------------------------------------
+    @staticmethod
+    def _rope_table(cfg: Qwen3Config) -> torch.Tensor:
+        half = cfg.head_dim // 2
+        inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, half, dtype=torch.float32) * 2.0 / cfg.head_dim))
+        ang = torch.arange(cfg.max_length, dtype=torch.float32)[:, None] * inv_freq[None, :]
+        return torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous()  # [max_len, 64, 2] fp32
+
+    @classmethod
+    def random_init(cls, config: Qwen3Config, seed: int = 0, device: Optional[torch.device] = None,
+                    std: float = 0.02) -> "Qwen3Encoder":
+        """Seeded random weights at the exact architecture (no checkpoint is reachable offline;
+        throughput is value-independent).  Generated on the device, layer by layer."""
+        enc = cls(config, device)
+        g = torch.Generator(device=enc.device).manual_seed(seed)
+
+        def w(*shape, scale=std):
+            return (torch.randn(*shape, generator=g, device=enc.device, dtype=torch.float32) * scale).to(torch.bfloat16)
+
+        def norm_w(n):
+            return (1.0 + 0.1 * torch.randn(n, generator=g, device=enc.device, dtype=torch.float32)).to(torch.bfloat16)
+
+        c = config
+        enc.embed = w(c.vocab_size, c.hidden_size)
+        for _ in range(c.num_layers):
+            enc.layers.append({
+                "ln1": norm_w(c.hidden_size), "ln2": norm_w(c.hidden_size),
+                "qkv": w(c.q_size + 2 * c.kv_size, c.hidden_size), "o": w(c.hidden_size, c.q_size),
+                "q_norm": norm_w(c.head_dim), "k_norm": norm_w(c.head_dim),
+                "gate_up": w(2 * c.intermediate_size, c.hidden_size), "down": w(c.hidden_size, c.intermediate_size),
+            })
+        enc.final_norm = norm_w(c.hidden_size)
+        return enc
+
+    @classmethod
+    def from_state_dict(cls, config: Qwen3Config, sd: Dict[str, torch.Tensor],
+                        device: Optional[torch.device] = None, prefix: str = "") -> "Qwen3Encoder":
+        """Load weights named like transformers' Qwen3Model (`layers.N.self_attn.q_proj.weight` ...)."""
+        enc = cls(config, device)
+
+        def get(name):
+            return sd[prefix + name].to(device=enc.device, dtype=torch.bfloat16).contiguous()
+
+        enc.embed = get("embed_tokens.weight")
+        for i in range(config.num_layers):
+            p = f"layers.{i}."
+            enc.layers.append({
+                "ln1": get(p + "input_layernorm.weight"), "ln2": get(p + "post_attention_layernorm.weight"),
+                "qkv": torch.cat([get(p + "self_attn.q_proj.weight"), get(p + "self_attn.k_proj.weight"),
+                                  get(p + "self_attn.v_proj.weight")], dim=0).contiguous(),
+                "o": get(p + "self_attn.o_proj.weight"),
+                "q_norm": get(p + "self_attn.q_norm.weight"), "k_norm": get(p + "self_attn.k_norm.weight"),
+                "gate_up": torch.cat([get(p + "mlp.gate_proj.weight"), get(p + "mlp.up_proj.weight")], dim=0).contiguous(),
+                "down": get(p + "mlp.down_proj.weight"),
+            })
+        enc.final_norm = get("norm.weight")
+        return enc
+
+    @classmethod
+    def from_pretrained(cls, path: str, device: Optional[torch.device] = None) -> "Qwen3Encoder":
+        """Local directory with config.json, *.safetensors and tokenizer files (nothing is fetched)."""
+        import json
+        from pathlib import Path
+
+        from safetensors.torch import load_file
+        root = Path(path)
+        hf = json.loads((root / "config.json").read_text())
+        rope = hf.get("rope_theta") or (hf.get("rope_parameters") or {}).get("rope_theta", 1_000_000.0)
+        cfg = Qwen3Config(hidden_size=hf["hidden_size"], num_layers=hf["num_hidden_layers"],
+                          num_heads=hf["num_attention_heads"], num_kv_heads=hf["num_key_value_heads"],
+                          head_dim=hf.get("head_dim", 128), intermediate_size=hf["intermediate_size"],
+                          vocab_size=hf["vocab_size"], rms_norm_eps=hf.get("rms_norm_eps", 1e-6), rope_theta=rope)
+        sd: Dict[str, torch.Tensor] = {}
+        for f in sorted(root.glob("*.safetensors")):
+            sd.update(load_file(str(f)))
+        prefix = "model." if any(k.startswith("model.") for k in sd) else ""
+        enc = cls.from_state_dict(cfg, sd, device, prefix=prefix)
+        from transformers import AutoTokenizer
+        enc.tokenizer = AutoTokenizer.from_pretrained(str(root), local_files_only=True)
+        return enc
+
+    # -- forward --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_packed(self, ids: torch.Tensor, batch: PackedBatch) -> torch.Tensor:
+        """ids: int32 [T] on the device.  Returns unit-norm embeddings [B, out_dim] fp32."""
+        c = self.cfg
+        if c.head_dim != 128:
+            raise ValueError("the HIP attention / rope kernels are specialised for head_dim 128")
+        t, dev = batch.n_tokens, self.device
+        bf = torch.bfloat16
+        x = torch.empty(t, c.hidden_size, dtype=bf, device=dev)
+        ops.embed_gather(ids, self.embed, x)
+        resid = torch.empty_like(x)
+        normed = torch.empty_like(x)
+        width = c.q_size + 2 * c.kv_size
+        qkv_buf = torch.zeros(t + 32, width, dtype=bf, device=dev)  # attention reads up to 31 rows past T
+        qkv = qkv_buf[:t]
+        vt = torch.empty(c.num_kv_heads, c.head_dim, batch.t_pad, dtype=bf, device=dev)
+        attn = torch.empty(t, c.q_size, dtype=bf, device=dev)
+        act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
+        scale = 1.0 / math.sqrt(c.head_dim)
+        delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
+        for i, L in enumerate(self.layers):
+            if i == 0:
+                ops.rmsnorm(x, L["ln1"], normed, c.rms_norm_eps, residual_in=None, residual_out=None)
+                resid.copy_(x)
+            else:
+                ops.rmsnorm(delta, L["ln1"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
+            torch.matmul(normed, L["qkv"].t(), out=qkv)
+            ops.qk_norm_rope(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
+                             c.num_heads, c.num_kv_heads, c.rms_norm_eps)
+            ops.v_transpose(qkv_buf, vt, batch.tok_of_pad, c.num_heads, c.num_kv_heads)
+            ops.attention(qkv_buf, vt, attn, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0,
+                          c.num_heads, c.num_kv_heads, scale)
+            delta = F.linear(attn, L["o"])
+            ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
+            gate_up = F.linear(normed, L["gate_up"])
+            ops.swiglu(gate_up, act)
+            delta = F.linear(act, L["down"])
+        out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
+        if c.pooling == "last":
+            # residual + last delta for the pooled rows only, then the final norm inside the pool kernel
+            final = torch.empty_like(x)
+            torch.add(resid, delta, out=final)
+            ops.pool_normalize(final, self.final_norm, batch.cu, out, c.out_dim, 0, c.rms_norm_eps)
+        elif c.pooling == "mean":
+            ops.rmsnorm(delta, self.final_norm, normed, c.rms_norm_eps, residual_in=resid, residual_out=None)
+            ops.pool_normalize(normed, None, batch.cu, out, c.out_dim, 1, c.rms_norm_eps)
+        else:
+            raise ValueError(f"unknown pooling {c.pooling!r}")
+        return out
+
+    @torch.no_grad()
+    def embed_token_lists(self, token_lists: Sequence[Sequence[int]]) -> torch.Tensor:
+        lens = [min(len(tl), self.cfg.max_length) for tl in token_lists]
+        flat = np.concatenate([np.asarray(tl[:n], dtype=np.int32) for tl, n in zip(token_lists, lens)])
+        batch = PackedBatch.build(lens, self.device)
+        ids = torch.from_numpy(flat).to(self.device)
+        return self.forward_packed(ids, batch)
+
+    # -- the Encoder protocol of cadence_rag_amd.embeddings ------------------------------------------
+    def encode(self, texts: Sequence[str]) -> Tuple[List[List[float]], str]:
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer loaded (Qwen3Encoder.from_pretrained, or set .tokenizer)")
+        enc = self.tokenizer(list(texts), truncation=True, max_length=self.cfg.max_length, padding=False)["input_ids"]
+        vecs = self.embed_token_lists(enc)
+        return vecs.cpu().tolist(), self.cfg.model_id
+
+
+class ByteTokenizer:
+    """Deterministic stand-in tokenizer for tests and synthetic benchmarks ONLY (utf-8 bytes + an
+    end marker).  Real deployments load the model's own tokenizer with from_pretrained."""
+
+    def __init__(self, eos_id: int = 256) -> None:
+        self.eos_id = eos_id
+
+    def __call__(self, texts, truncation=True, max_length=1024, padding=False):
+        out = []
+        for t in texts:
+            ids = list(t.encode("utf-8"))[: max_length - 1] + [self.eos_id]
+            out.append(ids)
+        return {"input_ids": out}

@@ -1,0 +1,73 @@
+/*
+ * crag_encoder.h — C ABI of the hand-written HIP operators of the Qwen3-Embedding encoder lane
+ * (libcrag_dense.so, gfx950).  They replace the arithmetic the reference delegates to an external
+ * Triton/ONNX gateway (/root/reference/app/embeddings.py:53-59 ->
+ * P620_TRITON_QWEN3_4B_EMBEDDING_RUNBOOK.md:618-649,683-716): everything of the decoder forward
+ * except the plain linear layers (library GEMMs), plus the gateway's pooling / slice / L2-norm
+ * post-processing (RUNBOOK:703-715).
+ *
+ * Conventions as in crag_dense.h: 0 = ok, negative = error (crag_last_error()); all pointers are
+ * DEVICE pointers on the current device; `stream` is a hipStream_t as void*.  bf16 tensors are
+ * raw uint16 storage, row-major.  Sequences are PACKED (no padding): T tokens total,
+ * cu_seqlens[B+1] int32 prefix sums.
+ */
+#ifndef CRAG_ENCODER_H
+#define CRAG_ENCODER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRAG_HEAD_DIM 128 /* Qwen3 head_dim; the attention / rope kernels are specialised for it */
+
+/* x[t, :] = table[ids[t], :]            (embed_tokens) */
+int crag_enc_embed_gather(const int32_t *ids, const uint16_t *table, uint16_t *out, int64_t n_tokens,
+                          int hidden, int64_t vocab, void *stream);
+
+/* RMSNorm with optional fused residual add (the pre-norm residual stream):
+ *   s = x (+ residual_in);  residual_out = s (if non-NULL);  out = weight * bf16(s * rsqrt(mean(s^2)+eps))
+ * rows x hidden, hidden % 8 == 0, hidden <= 8192. */
+int crag_enc_rmsnorm(const uint16_t *x, const uint16_t *residual_in, const uint16_t *weight,
+                     uint16_t *out, uint16_t *residual_out, int64_t rows, int hidden, float eps,
+                     void *stream);
+
+/* In-place per-head RMSNorm (q_norm / k_norm weights, [128]) + rotary embedding (rotate-half
+ * form) on the q and k parts of the fused projection qkv[T, (hq + 2*hkv) * 128];
+ * cos_sin[max_pos, 64, 2] fp32 table; positions[T] int32 (position inside its sequence). */
+int crag_enc_qk_norm_rope(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w,
+                          const float *cos_sin, const int32_t *positions, int64_t n_tokens, int hq,
+                          int hkv, float eps, void *stream);
+
+/* V part of qkv -> Vt[hkv][128][t_pad] (keys on the fast axis, each sequence starting at a
+ * 32-aligned padded offset, pads zero).  tok_of_pad[t_pad] int32: packed token of a padded slot
+ * or -1. */
+int crag_enc_v_transpose(const uint16_t *qkv, uint16_t *vt, const int32_t *tok_of_pad, int64_t t_pad,
+                         int hq, int hkv, void *stream);
+
+/* Causal grouped-query flash attention over packed sequences, head_dim 128, bf16 in/out,
+ * fp32 softmax and accumulation.  One workgroup per (q block of 32 rows, kv head): its 4 waves are
+ * the hq/hkv = 4 query heads of the group.  blk_seq / blk_q0 [n_blocks] int32: sequence and first
+ * row (inside the sequence) of every q block.  qkv rows must extend 32 rows past T (any finite or
+ * non-finite content).  out[T, hq*128]. */
+int crag_enc_attention(const uint16_t *qkv, const uint16_t *vt, uint16_t *out, const int32_t *cu_seqlens,
+                       const int32_t *cu_pad, const int32_t *blk_seq, const int32_t *blk_q0,
+                       int n_blocks, int64_t t_pad, int hq, int hkv, float scale, void *stream);
+
+/* out[t, i] = silu(gu[t, i]) * gu[t, inter + i]   (gate | up fused projection) */
+int crag_enc_swiglu(const uint16_t *gate_up, uint16_t *out, int64_t rows, int inter, void *stream);
+
+/* Pooling + post-processing of the gateway: per sequence take the last token (mode 0) or the
+ * mean over its tokens (mode 1) of the FINAL-NORMED hidden state, keep the first out_dim
+ * components, L2-normalise in fp32 with max(norm, 1e-12).  For mode 0 `hidden_states` is the
+ * un-normed residual stream and the final RMSNorm (weight, eps) is applied to the pooled rows
+ * only; for mode 1 it must already be normed (weight may be NULL).  out[B, out_dim] fp32. */
+int crag_enc_pool_normalize(const uint16_t *hidden_states, const uint16_t *final_norm_w,
+                            const int32_t *cu_seqlens, float *out, int n_seqs, int hidden, int out_dim,
+                            int mode, float eps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRAG_ENCODER_H */

@@ -6,12 +6,16 @@ from pathlib import Path
 
 from cadence_rag_amd import _native
 
-HEADER = Path(__file__).resolve().parent.parent / "include" / "crag_dense.h"
+INCLUDE = Path(__file__).resolve().parent.parent / "include"
+HEADER = INCLUDE / "crag_dense.h"
 
 
 def _declared_functions():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
-    return sorted(set(re.findall(r"\b(crag_[a-z_0-9]+)\s*\(", text)))
+    names = set()
+    for header in (HEADER, INCLUDE / "crag_encoder.h"):
+        text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+        names.update(re.findall(r"\b(crag_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_declares_expected_surface():

@@ -1,0 +1,254 @@
+"""Encoder lane: every hand-written HIP operator against a plain PyTorch fp32 reference of the same
+op, and the whole packed forward against transformers' Qwen3Model (fp32, CPU) built from a local
+config with seeded random weights — the only encoder oracle available offline."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+BF = torch.bfloat16
+
+
+def _bf(x):
+    return x.to(BF).to(DEV).contiguous()
+
+
+def test_embed_gather(gpu):
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(0)
+    table = _bf(torch.randn(1000, 256, generator=g))
+    ids = torch.randint(0, 1000, (77,), generator=g, dtype=torch.int32).to(DEV)
+    out = torch.empty(77, 256, dtype=BF, device=DEV)
+    ops.embed_gather(ids, table, out)
+    assert torch.equal(out, table[ids.long()])
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 8), (5, 256), (33, 2560), (7, 8192)])
+def test_rmsnorm_with_and_without_residual(gpu, rows, hidden):
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(rows * 31 + hidden)
+    x, r = _bf(torch.randn(rows, hidden, generator=g) * 3), _bf(torch.randn(rows, hidden, generator=g))
+    w = _bf(1 + 0.1 * torch.randn(hidden, generator=g))
+    eps = 1e-6
+
+    def ref(s_bf):
+        s = s_bf.float()
+        n = (s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + eps)).to(BF)
+        return (w.float() * n.float()).to(BF)
+
+    out = torch.empty_like(x)
+    ops.rmsnorm(x, w, out, eps)
+    assert torch.allclose(out.float(), ref(x).float(), atol=2e-2, rtol=2e-2)
+    res_out = torch.empty_like(x)
+    ops.rmsnorm(x, w, out, eps, residual_in=r, residual_out=res_out)
+    s = (x.float() + r.float()).to(BF)
+    assert torch.equal(res_out, s)
+    assert torch.allclose(out.float(), ref(s).float(), atol=2e-2, rtol=2e-2)
+
+
+def _rope_ref(x, pos, theta):
+    # x [T, H, 128] fp32, rotate-half form
+    half = 64
+    inv = 1.0 / (theta ** (torch.arange(0, half, dtype=torch.float32) * 2.0 / 128))
+    ang = pos.float()[:, None] * inv[None, :]
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1)[:, None, :], torch.cat([ang.sin(), ang.sin()], -1)[:, None, :]
+    rot = torch.cat([-x[..., half:], x[..., :half]], -1)
+    return x * cos + rot * sin
+
+
+def test_qk_norm_rope(gpu):
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import Qwen3Config, Qwen3Encoder
+    g = torch.Generator().manual_seed(3)
+    t, hq, hkv = 37, 4, 2
+    qkv = _bf(torch.randn(t + 32, (hq + 2 * hkv) * 128, generator=g))
+    qw, kw = _bf(1 + 0.1 * torch.randn(128, generator=g)), _bf(1 + 0.1 * torch.randn(128, generator=g))
+    pos = torch.randint(0, 500, (t,), generator=g, dtype=torch.int32)
+    cfg = Qwen3Config(max_length=512)
+    table = Qwen3Encoder._rope_table(cfg).to(DEV)
+    before = qkv.clone()
+    ops.qk_norm_rope(qkv, qw, kw, table, pos.to(DEV), hq, hkv, 1e-6)
+
+    def ref(block, w, heads):
+        v = block.float().cpu().view(t, heads, 128)
+        n = v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float().cpu()
+        return _rope_ref(n, pos, cfg.rope_theta).reshape(t, heads * 128)
+
+    q_ref = ref(before[:t, : hq * 128], qw, hq)
+    k_ref = ref(before[:t, hq * 128: (hq + hkv) * 128], kw, hkv)
+    assert torch.allclose(qkv[:t, : hq * 128].float().cpu(), q_ref, atol=3e-2, rtol=3e-2)
+    assert torch.allclose(qkv[:t, hq * 128: (hq + hkv) * 128].float().cpu(), k_ref, atol=3e-2, rtol=3e-2)
+    assert torch.equal(qkv[:, (hq + hkv) * 128:], before[:, (hq + hkv) * 128:])  # V untouched
+    assert torch.equal(qkv[t:], before[t:])  # rows past T untouched
+
+
+def _attn_ref(q, k, v, lens, hq, hkv):
+    # q [T, hq, 128], k/v [T, hkv, 128] fp32; causal per sequence, GQA
+    out = torch.zeros_like(q)
+    start = 0
+    for n in lens:
+        for h in range(hq):
+            kv = h // (hq // hkv)
+            s = (q[start:start + n, h] @ k[start:start + n, kv].T) / math.sqrt(128)
+            s = s.masked_fill(torch.triu(torch.ones(n, n, dtype=torch.bool), 1), float("-inf"))
+            out[start:start + n, h] = torch.softmax(s, -1) @ v[start:start + n, kv]
+        start += n
+    return out
+
+
+@pytest.mark.parametrize("lens,hq,hkv", [([1], 4, 1), ([31, 32, 33], 4, 2), ([5, 200, 64, 1, 97], 8, 2),
+                                         ([300, 17], 32, 8)])
+def test_v_transpose_and_attention(gpu, lens, hq, hkv):
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch
+    g = torch.Generator().manual_seed(sum(lens) + hq)
+    t = sum(lens)
+    width = (hq + 2 * hkv) * 128
+    qkv = torch.randn(t + 32, width, generator=g)
+    qkv[t:] = float("nan")  # rows past T may hold anything
+    qkv = _bf(qkv)
+    batch = PackedBatch.build(lens, DEV)
+    vt = torch.empty(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+    ops.v_transpose(qkv, vt, batch.tok_of_pad, hq, hkv)
+    v = qkv[:t, (hq + hkv) * 128:].view(t, hkv, 128)
+    tok = batch.tok_of_pad.long()
+    want_vt = torch.zeros(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+    want_vt[:, :, tok >= 0] = v[tok[tok >= 0]].permute(1, 2, 0)
+    assert torch.equal(vt, want_vt)
+    out = torch.empty(t, hq * 128, dtype=BF, device=DEV)
+    ops.attention(qkv, vt, out, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
+    f = qkv[:t].float().cpu()
+    ref = _attn_ref(f[:, : hq * 128].view(t, hq, 128), f[:, hq * 128: (hq + hkv) * 128].view(t, hkv, 128),
+                    f[:, (hq + hkv) * 128:].view(t, hkv, 128), lens, hq, hkv)
+    got = out.float().cpu().view(t, hq, 128)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, ref, atol=2e-2, rtol=2e-2), (got - ref).abs().max()
+
+
+def test_attention_rescale_branch_with_spiked_key(gpu):
+    """Force a large running-max jump at a late key tile (cdna guide rule 26)."""
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch
+    g = torch.Generator().manual_seed(9)
+    lens, hq, hkv = [160], 4, 1
+    t = 160
+    qkv = torch.randn(t + 32, (hq + 2 * hkv) * 128, generator=g) * 0.5
+    qkv[130, hq * 128: (hq + 1) * 128] = qkv[150, :128] * 6.0  # key 130 aligned with query 150 of head 0
+    qkv = _bf(qkv)
+    batch = PackedBatch.build(lens, DEV)
+    vt = torch.empty(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+    ops.v_transpose(qkv, vt, batch.tok_of_pad, hq, hkv)
+    out = torch.empty(t, hq * 128, dtype=BF, device=DEV)
+    ops.attention(qkv, vt, out, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
+    f = qkv[:t].float().cpu()
+    ref = _attn_ref(f[:, : hq * 128].view(t, hq, 128), f[:, hq * 128: (hq + hkv) * 128].view(t, hkv, 128),
+                    f[:, (hq + hkv) * 128:].view(t, hkv, 128), lens, hq, hkv)
+    assert torch.allclose(out.float().cpu().view(t, hq, 128), ref, atol=2e-2, rtol=2e-2)
+
+
+def test_swiglu(gpu):
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(4)
+    gu = _bf(torch.randn(19, 2 * 9728, generator=g) * 2)
+    out = torch.empty(19, 9728, dtype=BF, device=DEV)
+    ops.swiglu(gu, out)
+    gate, up = gu[:, :9728].float(), gu[:, 9728:].float()
+    ref = (torch.nn.functional.silu(gate).to(BF).float() * up).to(BF)
+    assert torch.allclose(out.float(), ref.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_pool_normalize(gpu, mode):
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(5)
+    lens = [3, 1, 10]
+    hs = _bf(torch.randn(sum(lens), 256, generator=g))
+    w = _bf(1 + 0.1 * torch.randn(256, generator=g))
+    cu = torch.tensor([0, 3, 4, 14], dtype=torch.int32, device=DEV)
+    out = torch.empty(3, 64, dtype=torch.float32, device=DEV)
+    ops.pool_normalize(hs, w if mode == 0 else None, cu, out, 64, mode, 1e-6)
+    rows = []
+    for b in range(3):
+        seg = hs[cu[b]:cu[b + 1]].float()
+        if mode == 0:
+            x = seg[-1]
+            x = (w.float() * (x * torch.rsqrt(x.pow(2).mean() + 1e-6)).to(BF).float()).to(BF).float()
+        else:
+            x = seg.mean(0)
+        x = x[:64]
+        rows.append(x / x.norm().clamp_min(1e-12))
+    ref = torch.stack(rows)
+    assert torch.allclose(out, ref, atol=5e-3, rtol=5e-3)
+    assert torch.allclose(out.norm(dim=1), torch.ones(3, device=DEV), atol=1e-5)
+
+
+def _tiny_hf_and_mine(pooling="last"):
+    from transformers import Qwen3Config as HFConfig
+    from transformers.models.qwen3.modeling_qwen3 import Qwen3Model
+    from cadence_rag_amd.encoder.qwen3 import Qwen3Config, Qwen3Encoder
+    torch.manual_seed(1234)
+    hf_cfg = HFConfig(vocab_size=503, hidden_size=256, intermediate_size=512, num_hidden_layers=3,
+                      num_attention_heads=4, num_key_value_heads=2, head_dim=128, rms_norm_eps=1e-6,
+                      max_position_embeddings=1024, rope_parameters={"rope_theta": 1_000_000.0, "rope_type": "default"},
+                      attention_bias=False, tie_word_embeddings=False)
+    model = Qwen3Model(hf_cfg).eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "norm" in name:
+                p.copy_(1 + 0.1 * torch.randn_like(p))
+            else:
+                p.copy_(torch.randn_like(p) * 0.05)
+            p.copy_(p.to(BF).float())  # the encoder holds bf16 weights: give the oracle the same values
+    cfg = Qwen3Config(hidden_size=256, num_layers=3, num_heads=4, num_kv_heads=2, head_dim=128, intermediate_size=512,
+                      vocab_size=503, out_dim=64, pooling=pooling, max_length=1024)
+    enc = Qwen3Encoder.from_state_dict(cfg, model.state_dict(), DEV)
+    return model, enc, cfg
+
+
+def _hf_embed(model, cfg, token_lists, pooling):
+    outs = []
+    with torch.no_grad():
+        for ids in token_lists:  # one unpadded sequence at a time: the gateway's batch-of-1 case
+            h = model(input_ids=torch.tensor([ids])).last_hidden_state[0]
+            v = (h[-1] if pooling == "last" else h.mean(0))[: cfg.out_dim].float()
+            outs.append(v / v.norm().clamp_min(1e-12))
+    return torch.stack(outs)
+
+
+@pytest.mark.parametrize("pooling", ["last", "mean"])
+def test_full_forward_matches_transformers_qwen3(gpu, pooling):
+    model, enc, cfg = _tiny_hf_and_mine(pooling)
+    rng = np.random.default_rng(7)
+    token_lists = [rng.integers(0, 503, size=n).tolist() for n in (1, 7, 32, 33, 150, 64, 257)]
+    got = enc.embed_token_lists(token_lists).cpu()
+    want = _hf_embed(model, cfg, token_lists, pooling)
+    cos = (got * want).sum(-1)
+    assert torch.allclose(got.norm(dim=1), torch.ones(len(token_lists)), atol=1e-4)
+    assert cos.min() > 0.995, cos          # bf16 pipeline vs fp32 oracle
+    assert (got - want).abs().max() < 0.03
+
+
+def test_packed_batch_equals_one_by_one_and_encoder_protocol(gpu, monkeypatch):
+    from cadence_rag_amd import embeddings
+    from cadence_rag_amd.config import settings
+    from cadence_rag_amd.encoder.qwen3 import ByteTokenizer
+    _, enc, cfg = _tiny_hf_and_mine()
+    enc.tokenizer = ByteTokenizer(eos_id=300)
+    texts = ["hello world", "a", "the quick brown fox jumps over the lazy dog " * 3]
+    batch_vecs, model_id = enc.encode(texts)
+    singles = [enc.encode([t])[0][0] for t in texts]
+    # packing changes nothing beyond bf16 GEMM rounding (the library picks other tilings per M)
+    assert np.allclose(np.array(batch_vecs), np.array(singles), atol=1e-2)
+    assert (np.array(batch_vecs) * np.array(singles)).sum(-1).min() > 0.9995
+    monkeypatch.setattr(settings, "embeddings_base_url", "native")
+    monkeypatch.setattr(settings, "embeddings_dim", cfg.out_dim)
+    embeddings.set_encoder(enc)
+    try:
+        res = embeddings.embed_texts(["  hello world  ", "", "a"])  # blanks dropped, texts stripped
+        assert len(res.vectors) == 2 and res.model == model_id
+        assert np.allclose(res.vectors[0], batch_vecs[0], atol=1e-2)  # batch of 2 vs 3: other GEMM tiling
+    finally:
+        embeddings.set_encoder(None)
