@@ -77,6 +77,55 @@ def cpu_baseline(corpus_host: np.ndarray, queries_host: np.ndarray, gpu_ids: np.
     }, recall, same_order
 
 
+def encode_leg(dev, rank: int, world: int, dist, steps: int):
+    """chunks embedded/sec (second half of BASELINE.json's metric; configs[3] shape): batch = 256
+    synthetic chunks, lengths ~N(256, 96) clipped to [8, 1024] and rescaled to mean 256, packed (no
+    pad FLOPs), full Qwen3-Embedding-4B architecture with seeded random bf16 weights (no checkpoint
+    is reachable offline; throughput is value-independent).  Data-parallel replicas: no collective."""
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch, Qwen3Config, Qwen3Encoder
+
+    cfg = Qwen3Config()
+    enc = Qwen3Encoder.random_init(cfg, seed=1234, device=dev)
+    rng = np.random.default_rng(2024 + rank)
+    n_chunks = 256
+    lens = np.clip(rng.normal(256, 96, size=n_chunks).round().astype(int), 8, 1024)
+    lens = (lens * (256 * n_chunks / lens.sum())).round().astype(int).clip(8, 1024)
+    batch = PackedBatch.build(lens, dev)
+    ids = torch.from_numpy(rng.integers(0, cfg.vocab_size, size=int(lens.sum())).astype(np.int32)).to(dev)
+    enc.forward_packed(ids, batch)  # warmup (GEMM autotune, allocator)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = enc.forward_packed(ids, batch)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tokens = int(lens.sum())
+    ctx = float((lens.astype(float) ** 2).sum() / lens.sum())
+    tflops = cfg.flops_per_token(ctx) * tokens * steps / dt / 1e12
+    ok = bool(torch.isfinite(out).all().item()) and bool(torch.allclose(out.norm(dim=1), torch.ones(n_chunks, device=dev), atol=1e-3))
+    del enc
+    torch.cuda.empty_cache()
+    return {
+        "metric": "chunks embedded/sec", "value": round(world * n_chunks * steps / dt, 2), "unit": "chunks/sec",
+        "tokens_per_s": round(world * tokens * steps / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 2),
+        "steps": steps, "batch_chunks": n_chunks, "avg_tokens": round(tokens / n_chunks, 1), "dtype": "bf16",
+        "model": "Qwen3-Embedding-4B architecture (36L, 2560h, 32q/8kv x128, 9728 ffn), seeded random weights",
+        "pooling": "last token -> [:1024] -> L2 normalise", "parallelism": "replicas" if world > 1 else "1 GPU",
+        "outputs_unit_norm": ok,
+        "roofline": {"bound": "mfma", "achieved": round(tflops / world, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(tflops / world / 2500.0, 4), "traffic": None,
+                     "note": "whole forward (library GEMMs + HIP ops), algorithmic FLOPs 2*P + causal attention"},
+    }
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +135,8 @@ def main() -> None:
     ap.add_argument("--queries", type=int, default=QUERIES_PER_STEP)
     ap.add_argument("--topk", type=int, default=TOPK)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
+    ap.add_argument("--encode-steps", type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +208,10 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    encode = None
+    if not args.no_encode:
+        encode = encode_leg(dev, rank, world, dist, args.encode_steps)
+
     if rank == 0:
         geo = index.scan_geometry(nq)
         scan_avg_s = scan_ms / max(n_launch, 1) / 1e3
@@ -194,6 +249,9 @@ def main() -> None:
                 "workgroups": geo["workgroups"], "launches_timed": n_launch,
             },
         }
+        if encode is not None:
+            line["encode"] = encode
+            line["config"]["encode"] = "see top-level 'encode' (chunks embedded/sec, BASELINE configs[3] shape)"
         if not args.no_cpu_baseline:
             # rank 0's own shard result (before the cross-shard merge) vs the oracle on that shard
             base, recall, same_order = cpu_baseline(corpus.cpu().numpy(), queries.cpu().numpy(),
