@@ -124,7 +124,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                   int64_t mask_stride, int64_t *d_out_ids, float *d_out_scores, int32_t *d_out_counts,
                   hipStream_t st) {
     if (nq <= 0) return CRAG_OK;
-    const int q_blocks = (nq + 31) / 32;
+    int q_blocks = (nq + 31) / 32;
+    // more than 32 queries and k <= 32: the 64-queries-per-pass kernel (two query blocks per pass)
+    const bool wide = (nq > 32) && (k <= 32) && !getenv("CRAG_NO_WIDE");
+    if (wide) q_blocks = ((nq + 63) / 64) * 2;
     const int G = scan_groups(ix);
     int rc;
     if ((rc = ix->partial.ensure((size_t)q_blocks * G * 32 * (size_t)k * sizeof(uint2)))) return rc;
@@ -143,6 +146,12 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                     (long long)ix->size);
 
     crag::ScanParams sp;
+    sp.qtiles = nullptr;
+    if (wide) {
+        if ((rc = ix->qtiles.ensure((size_t)q_blocks * crag::TILE_FLOATS * sizeof(float)))) return rc;
+        HIP_TRY(crag::launch_prep_queries(d_queries, nq, ix->dim, (float *)ix->qtiles.p, q_blocks, st));
+        sp.qtiles = (const float *)ix->qtiles.p;
+    }
     sp.corpus = ix->corpus;
     sp.inv_norm = ix->inv_norm;
     sp.queries = d_queries;

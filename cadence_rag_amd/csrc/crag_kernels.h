@@ -17,6 +17,7 @@ struct ScanParams {
     const float *corpus;      // tile32 layout
     const float *inv_norm;    // [cap_rows] 1/||row||, 0 = never eligible
     const float *queries;     // [nq, dim] row-major fp32 (raw; normalised in-kernel)
+    const float *qtiles;      // non-NULL: normalised queries in tile32 layout -> 64-query kernel
     const uint32_t *mask;     // nullable; 32 rows per word
     int64_t mask_stride_w;    // words between consecutive queries' masks (0 = shared)
     uint2 *partial;           // [q_blocks][G][32][k] keys
@@ -63,7 +64,7 @@ hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n,
                              float *inv_norm, hipStream_t st);
 hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
                             hipStream_t st);
-hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, hipStream_t st);
+hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, int q_blocks, hipStream_t st);
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,
                                  unsigned long long *out, hipStream_t st);
 hipError_t launch_fill_ids(int64_t *ids, int64_t pos, int64_t n, int64_t first, hipStream_t st);

@@ -673,6 +673,260 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     }
 }
 
+// ---- pipelined kernel for 64 queries per pass (k <= 32).  Intensity doubles (32 flop/B): the
+// pass is bound by the fp32 matrix pipe, not HBM.  Each wave multiplies every loaded B fragment
+// with TWO query blocks; the A fragments no longer fit in registers beside the selection state, so
+// they are streamed from L2 (the prepared, normalised tile32 copy of the queries) through an
+// 8-deep register ring exactly like B.  Reduction/selection ops of both query blocks are spread
+// over the 128 MFMA slots of the next tile. -----------------------------------------------------
+struct Pipe2Tile {
+    uint32_t nrow;
+    float scale[2][2];    // [query block][e]
+    uint32_t tauh[2][2];
+};
+
+struct Pipe2State {
+    float2 rd[4];
+    float d[2];
+    HalfList<1> list[2][2];
+    uint32_t th[2][2], tl[2][2], pub[2][2];
+    PipeSel n;  // h/l/ph/pl/active are reused by the two query blocks one after the other
+};
+
+struct Pipe2Ctx {
+    int qloc[2];
+    bool qok[2][2];
+    int qglob[2][2];
+};
+
+template <int OP, int QB>
+__device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx &c2,
+                                         float2 (*slab)[SCAN_WAVES][2][8][64], int rbuf, const Pipe2Tile &pt,
+                                         Pipe2State &st) {
+    const int lane = c.lane;
+    PipeSel &n = st.n;
+    if constexpr (OP == 0) {
+        if constexpr (QB == 0) __syncthreads();
+    } else if constexpr (OP == 1) {  // partial sums of producer waves 0..3
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = slab[rbuf][ww][QB][c.w][lane];
+    } else if constexpr (OP == 2) {  // add them (fixed order) and fetch producers 4..7 into the same registers
+        st.d[0] = ((st.rd[0].x + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
+        st.d[1] = ((st.rd[0].y + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = slab[rbuf][4 + ww][QB][c.w][lane];
+    } else if constexpr (OP == 3) {
+        st.d[0] = (((st.d[0] + st.rd[0].x) + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
+        st.d[1] = (((st.d[1] + st.rd[0].y) + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
+    } else if constexpr (OP == 4 || OP == 5) {
+        constexpr int e = OP - 4;
+        float sc = st.d[e] * pt.scale[QB][e];
+        sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);
+        const bool ok = (pt.scale[QB][e] > 0.f) && (sc == sc);
+        const uint32_t u = __float_as_uint(sc);
+        const uint32_t ord = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+        n.h[e] = ok ? ord : 0u;
+        n.l[e] = ok ? pt.nrow : 0u;
+    } else if constexpr (OP == 6) {
+        const bool beats =
+            ((mk64(n.h[0], n.l[0]) > mk64(st.th[QB][0], st.tl[QB][0])) && (n.h[0] >= pt.tauh[QB][0])) ||
+            ((mk64(n.h[1], n.l[1]) > mk64(st.th[QB][1], st.tl[QB][1])) && (n.h[1] >= pt.tauh[QB][1]));
+        n.active = __any(beats);
+        if (n.active) net_issue<SortStage<0>::X>(n);
+    } else if constexpr (OP >= 7 && OP <= 20) {
+        if (n.active) {
+            net_consume<SortStage<OP - 7>::BIT>(n, lane);
+            net_issue<SortStage<OP - 6>::X>(n);
+        }
+    } else if constexpr (OP == 21) {
+        if (n.active) {
+            net_consume<SortStage<14>::BIT>(n, lane);
+            net_issue<31>(n);
+        }
+    } else if constexpr (OP == 22) {
+        if (n.active) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool gt = mk64(n.ph[e], n.pl[e]) > mk64(st.list[QB][e].hi[0], st.list[QB][e].lo[0]);
+                n.h[e] = gt ? n.ph[e] : st.list[QB][e].hi[0];
+                n.l[e] = gt ? n.pl[e] : st.list[QB][e].lo[0];
+            }
+            net_issue<SortStage<16>::X>(n);
+        }
+    } else if constexpr (OP >= 23 && OP <= 26) {
+        if (n.active) {
+            net_consume<SortStage<OP - 7>::BIT>(n, lane);
+            net_issue<SortStage<OP - 6>::X>(n);
+        }
+    } else if constexpr (OP == 27) {
+        if (n.active) {
+            net_consume<SortStage<20>::BIT>(n, lane);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                st.list[QB][e].hi[0] = n.h[e];
+                st.list[QB][e].lo[0] = n.l[e];
+                const uint64_t t = st.list[QB][e].kth(p.k, lane);
+                st.th[QB][e] = (uint32_t)(t >> 32);
+                st.tl[QB][e] = (uint32_t)t;
+                if ((lane & 31) == 0 && c2.qok[QB][e] && n.h[e] > st.pub[QB][e]) {
+                    st.pub[QB][e] = n.h[e];
+                    (void)__hip_atomic_fetch_max(p.gbound + (size_t)c2.qglob[QB][e] * GB_CELLS + (c.g % p.k), n.h[e],
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) {
+    __shared__ float2 slab[2][SCAN_WAVES][2][8][64];  // 128 KiB
+    const ScanCtx c = make_ctx(p);                     // row range; its query fields are not used here
+    const int lane = c.lane, w = c.w, j = c.j;
+    Pipe2Ctx c2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = 2 * w + e;
+        c2.qloc[e] = (r & 3) + 8 * (r >> 2) + 4 * c.h;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            c2.qglob[qb][e] = (blockIdx.y * 2 + qb) * 32 + c2.qloc[e];
+            c2.qok[qb][e] = c2.qglob[qb][e] < p.nq;
+        }
+    }
+    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
+    const f32x4 *qa[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+        qa[qb] = reinterpret_cast<const f32x4 *>(p.qtiles + (size_t)(blockIdx.y * 2 + qb) * TILE_FLOATS + w * (KSLICE * 32)) + lane;
+
+    // rings: B (from HBM) 8 deep, slot s & 7 serves steps s and s + 8; A (from L2) 4 deep
+    u32x4 b[8];
+    f32x4 a[2][4];
+    uint32_t vcur = tile_voff(c, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + s * 1024, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[0][s] = qa[0][s * 64];
+        a[1][s] = qa[1][s * 64];
+    }
+
+    Pipe2State st;
+    st.n.active = false;
+    st.d[0] = st.d[1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        st.n.h[e] = st.n.l[e] = st.n.ph[e] = st.n.pl[e] = st.n.th[e] = st.n.tl[e] = st.n.pub[e] = 0u;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            st.list[qb][e].clear();
+            st.th[qb][e] = st.tl[qb][e] = st.pub[qb][e] = 0u;
+        }
+    }
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) st.rd[ww] = make_float2(0.f, 0.f);
+    Pipe2Tile prev;
+    prev.nrow = 0u;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            prev.scale[qb][e] = 0.f;
+            prev.tauh[qb][e] = 0u;
+        }
+
+    int wbuf = 0;
+    for (int ti = 0; ti < c.n_tiles; ++ti) {
+        const uint32_t vnext = tile_voff(c, ti + 1);
+        const int64_t tile = c.t_begin + tile_of(c, ti);
+        const int64_t row = tile * 32 + j;
+        const float inv_row = p.inv_norm[row];
+        uint32_t mword[2][2], gbv[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) mword[qb][e] = gbv[qb][e] = 0xffffffffu;
+        Pipe2Tile cur;
+        cur.nrow = ~(uint32_t)row;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                cur.scale[qb][e] = 0.f;
+                cur.tauh[qb][e] = 0u;
+            }
+
+        f32x16 acc[2];
+        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc[1] = acc[0];
+        static_for<0, 128>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            constexpr int s = m >> 3, cc = (m >> 1) & 3, qb = m & 1, slot = s & 7, aslot = s & 3;
+            acc[qb] = CRAG_MFMA(a[qb][aslot][cc], b[slot][cc], acc[qb]);
+            if constexpr ((m & 7) == 7) {  // slots fully consumed: refill B for step s + 8, A for step s + 4
+                if constexpr (s < 8) b[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + (s + 8) * 1024, 0, 0);
+                else b[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (s - 8) * 1024, 0, 0);
+                a[0][aslot] = qa[0][((s + 4) & 15) * 64];
+                a[1][aslot] = qa[1][((s + 4) & 15) * 64];
+            }
+            if constexpr ((m & 1) == 0) {
+                constexpr int o = m >> 1;
+                if constexpr (o < PIPE_OPS) pipe2_bg<o, 0>(p, c, c2, slab, wbuf ^ 1, prev, st);
+                else if constexpr (o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, 1>(p, c, c2, slab, wbuf ^ 1, prev, st);
+            }
+            if constexpr (m == 64) {  // epilogue operands of this tile, consumed from slot 113 on
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (p.mask)
+                            mword[q2][e] = p.mask[(size_t)(c2.qok[q2][e] ? c2.qglob[q2][e] : 0) * (size_t)p.mask_stride_w + tile];
+                        if (j < p.k && c2.qok[q2][e])
+                            gbv[q2][e] = __hip_atomic_load(p.gbound + (size_t)c2.qglob[q2][e] * GB_CELLS + j,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            }
+            if constexpr (m == 113) {
+                const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_row > 0.f);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+                        cur.scale[q2][e] = (row_ok && c2.qok[q2][e] && ((mword[q2][e] >> j) & 1u)) ? inv_row : 0.f;
+            }
+            if constexpr (m == 115 || m == 117 || m == 119 || m == 121) {
+                constexpr int idx = (m - 115) >> 1, q2 = idx >> 1, e = idx & 1;
+                cur.tauh[q2][e] = half_min_u32(gbv[q2][e]);
+                const uint32_t mine = (uint32_t)__shfl((int)gbv[q2][e], (lane & 32) | (c.g % p.k));
+                st.pub[q2][e] = mine > st.pub[q2][e] ? mine : st.pub[q2][e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr)
+                slab[wbuf][w][qb][pr][lane] = make_float2(acc[qb][2 * pr], acc[qb][2 * pr + 1]);
+        wbuf ^= 1;
+        prev = cur;
+        vcur = vnext;
+    }
+    if (c.n_tiles > 0) {
+        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 0>(p, c, c2, slab, wbuf ^ 1, prev, st); });
+        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 1>(p, c, c2, slab, wbuf ^ 1, prev, st); });
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (!c2.qok[qb][e]) continue;
+            uint2 *dst = p.partial + (((size_t)(blockIdx.y * 2 + qb) * p.G + c.g) * 32 + c2.qloc[e]) * (size_t)p.k;
+            if (j < p.k) dst[j] = make_uint2(st.list[qb][e].hi[0], st.list[qb][e].lo[0]);
+        }
+}
+
 // ------------------------------------------------------------------------------------------
 // merge of the per-workgroup lists: one 256-thread workgroup per query
 // ------------------------------------------------------------------------------------------
@@ -1047,6 +1301,11 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // ------------------------------------------------------------------------------------------
 hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st) {
     dim3 grid(p.G, q_blocks), block(SCAN_THREADS);
+    if (p.qtiles) {  // 64 queries per pass (q_blocks is even): the MFMA-bound kernel
+        dim3 grid2(p.G, q_blocks / 2);
+        hipLaunchKernelGGL(scan_pipe2_kernel, grid2, block, 0, st, p);
+        return hipGetLastError();
+    }
     if (p.k <= 32 && p.debug_mode == 2)
         hipLaunchKernelGGL(scan_pipe_kernel<2>, grid, block, 0, st, p);
     else if (p.k <= 32 && p.debug_mode == 4)
@@ -1103,8 +1362,8 @@ hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n
     return hipGetLastError();
 }
 
-hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, hipStream_t st) {
-    const int slots = ((nq + 31) / 32) * 32;
+hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, int q_blocks, hipStream_t st) {
+    const int slots = q_blocks * 32;
     hipLaunchKernelGGL(prep_queries_kernel, dim3(slots), dim3(256), 0, st, queries, nq, dim, qtiles);
     return hipGetLastError();
 }

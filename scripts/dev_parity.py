@@ -36,7 +36,7 @@ def run(n, nq, k, seed=0, mask_frac=None, dup=False):
     ix.close()
     return ok_ids
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("CRAG_SKIP_MAIN"):
     allok = True
     for args in [(1000, 3, 10), (257, 1, 5), (31, 2, 10), (4096, 32, 10), (20000, 33, 50), (50000, 64, 100),
                  (100000, 32, 10)]:
@@ -45,3 +45,10 @@ if __name__ == "__main__":
     allok &= run(5000, 8, 10, mask_frac=0.001)
     allok &= run(3000, 4, 20, dup=True)
     print("ALL OK" if allok else "FAILURES")
+    # 64-queries-per-pass kernel (nq > 32, k <= 32)
+    ok2 = True
+    for args in [(4096, 64, 10), (20000, 33, 10), (50000, 100, 32), (100000, 64, 10), (777, 65, 5)]:
+        ok2 &= run(*args)
+    ok2 &= run(5000, 40, 10, mask_frac=0.1)
+    ok2 &= run(3000, 64, 20, dup=True)
+    print("WIDE ALL OK" if ok2 else "WIDE FAILURES")
