@@ -28,7 +28,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 ROWS_PER_GPU = 100_000
 DIM = 1024
 TOPK = 10
-QUERIES_PER_STEP = 32
+QUERIES_PER_STEP = 64   # one pass of the 64-query kernel (two 32-query MFMA blocks per corpus fragment)
+FP32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
@@ -134,6 +135,9 @@ def main() -> None:
     ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
     ap.add_argument("--queries", type=int, default=QUERIES_PER_STEP)
     ap.add_argument("--topk", type=int, default=TOPK)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="issue consecutive steps round-robin on this many HIP streams (independent query "
+                         "batches may overlap on the GPU); 1 = strictly one step after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--encode-steps", type=int, default=3)
@@ -177,8 +181,18 @@ def main() -> None:
         f_ct = torch.empty_like(out_ct)
 
     stream = torch.cuda.current_stream().cuda_stream
+    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1) - 1)] if world == 1 else []
+    lanes = [(stream, out_ids, out_sc, out_ct)] + [
+        (s.cuda_stream, torch.empty_like(out_ids), torch.empty_like(out_sc), torch.empty_like(out_ct))
+        for s in extra_streams]
+    counter = [0]
 
     def step() -> None:
+        if len(lanes) > 1:  # independent batches, round-robin over the streams
+            st_, oi_, os_, oc_ = lanes[counter[0] % len(lanes)]
+            counter[0] += 1
+            index.search_async(queries, k, oi_, os_, oc_, stream=st_)
+            return
         index.search_async(queries, k, out_ids, out_sc, out_ct, stream=stream)
         if world > 1:  # the path's one exchange step: 12*Q*k bytes per rank over xGMI
             dist.all_gather_into_tensor(g_ids, out_ids)
@@ -216,6 +230,12 @@ def main() -> None:
         geo = index.scan_geometry(nq)
         scan_avg_s = scan_ms / max(n_launch, 1) / 1e3
         achieved = geo["algorithmic_bytes"] / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
+        # fp32 MFMA work of one launch: 2*Q*N*D with Q rounded up to whole 32-query MFMA blocks
+        q_pad = ((nq + 31) // 32) * 32
+        flops = 2.0 * q_pad * rows * DIM
+        tflops = flops / scan_avg_s / 1e12 if scan_avg_s > 0 else 0.0
+        # > 32 queries per pass: intensity Q/2 = 32 flop/B is past the 19.7 flop/B ridge -> matrix-pipe bound
+        mfma_bound = nq > 32 and k <= 32
         traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
         if os.path.exists(tpath) and rows == ROWS_PER_GPU and nq == QUERIES_PER_STEP:
@@ -235,15 +255,23 @@ def main() -> None:
                 "workload": f"BASELINE configs[1]: brute-force cosine top-{k}, {rows}x{DIM} fp32 corpus "
                             f"per GPU, {nq} queries/step resident in HBM",
                 "rows_per_gpu": rows, "rows_total": rows * world, "dim": DIM, "k": k,
-                "queries_per_step": nq,
+                "queries_per_step": nq, "streams": len(lanes),
                 "parallelism": "1 GPU" if world == 1 else f"corpus sharded x{world}, all-gather top-k merge",
                 "distinct_queries_per_s": round(nq * args.steps / elapsed, 2),
                 "encode": "not included in this step (encoder lane reported separately when built)",
             },
-            "roofline": {
+            "roofline": ({
+                "bound": "mfma", "achieved": round(tflops, 1), "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": round(tflops / FP32_MFMA_PEAK_TFS, 4), "traffic": traffic,
+                "kernel": "crag::scan_pipe2_kernel", "kernel_avg_us": round(scan_avg_s * 1e6, 2),
+                "hbm_achieved_gbs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+            } if mfma_bound else {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "crag::scan_pipe_kernel<0>", "kernel_avg_us": round(scan_avg_s * 1e6, 2),
+                "kernel": "crag::scan_pipe_kernel<0>" if k <= 32 else "crag::scan_kernel<S>",
+                "kernel_avg_us": round(scan_avg_s * 1e6, 2),
+                "mfma_tflops": round(tflops, 1), "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFS, 4),
+            }) | {
                 "merge_avg_us": round(merge_ms / max(n_launch, 1) * 1e3, 2),
                 "algorithmic_bytes_per_launch": geo["algorithmic_bytes"],
                 "workgroups": geo["workgroups"], "launches_timed": n_launch,

@@ -88,7 +88,15 @@ struct crag_index {
     float *corpus = nullptr;
     float *inv_norm = nullptr;
     int64_t *ids = nullptr;
-    DevBuf qtiles, partial, gbound, stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
+    // search workspaces are per stream (up to MAX_WS streams): searches enqueued on different streams
+    // may overlap on the GPU, same-stream searches are ordered by the stream itself
+    static constexpr int MAX_WS = 4;
+    struct Workspace {
+        hipStream_t stream = nullptr;
+        bool in_use = false;
+        DevBuf qtiles, partial, gbound;
+    } ws[MAX_WS];
+    DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
     int pass_parity = 0;  // alternate scan direction between searches (Infinity Cache reuse)
     int profiling = 0;      // 0 = off, N = record HIP events around every N-th search
@@ -130,12 +138,24 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     if (wide) q_blocks = ((nq + 63) / 64) * 2;
     const int G = scan_groups(ix);
     int rc;
-    if ((rc = ix->partial.ensure((size_t)q_blocks * G * 32 * (size_t)k * sizeof(uint2)))) return rc;
+    crag_index::Workspace *ws = nullptr;
+    for (auto &w : ix->ws)
+        if (w.in_use && w.stream == st) ws = &w;
+    if (!ws)
+        for (auto &w : ix->ws)
+            if (!w.in_use) {
+                w.in_use = true;
+                w.stream = st;
+                ws = &w;
+                break;
+            }
+    if (!ws) return fail(CRAG_EINVAL, "more than %d distinct streams used with one index", crag_index::MAX_WS);
+    if ((rc = ws->partial.ensure((size_t)q_blocks * G * 32 * (size_t)k * sizeof(uint2)))) return rc;
     {
         const size_t gb_bytes = (size_t)q_blocks * 32 * crag::GB_CELLS * sizeof(uint32_t);
-        if (gb_bytes > ix->gbound.bytes) {  // (re)allocated buffers start zeroed; merge re-zeroes after use
-            if ((rc = ix->gbound.ensure(gb_bytes))) return rc;
-            HIP_TRY(hipMemsetAsync(ix->gbound.p, 0, ix->gbound.bytes, st));
+        if (gb_bytes > ws->gbound.bytes) {  // (re)allocated buffers start zeroed; merge re-zeroes after use
+            if ((rc = ws->gbound.ensure(gb_bytes))) return rc;
+            HIP_TRY(hipMemsetAsync(ws->gbound.p, 0, ws->gbound.bytes, st));
         }
     }
 
@@ -148,9 +168,9 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     crag::ScanParams sp;
     sp.qtiles = nullptr;
     if (wide) {
-        if ((rc = ix->qtiles.ensure((size_t)q_blocks * crag::TILE_FLOATS * sizeof(float)))) return rc;
-        HIP_TRY(crag::launch_prep_queries(d_queries, nq, ix->dim, (float *)ix->qtiles.p, q_blocks, st));
-        sp.qtiles = (const float *)ix->qtiles.p;
+        if ((rc = ws->qtiles.ensure((size_t)q_blocks * crag::TILE_FLOATS * sizeof(float)))) return rc;
+        HIP_TRY(crag::launch_prep_queries(d_queries, nq, ix->dim, (float *)ws->qtiles.p, q_blocks, st));
+        sp.qtiles = (const float *)ws->qtiles.p;
     }
     sp.corpus = ix->corpus;
     sp.inv_norm = ix->inv_norm;
@@ -158,8 +178,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     sp.dim = ix->dim;
     sp.mask = (const uint32_t *)d_mask;
     sp.mask_stride_w = mask_stride / 4;
-    sp.partial = (uint2 *)ix->partial.p;
-    sp.gbound = (uint32_t *)ix->gbound.p;
+    sp.partial = (uint2 *)ws->partial.p;
+    sp.gbound = (uint32_t *)ws->gbound.p;
     sp.n_rows = ix->size;
     sp.cap_rows = ix->cap_rows;
     sp.nq = nq;
@@ -191,9 +211,9 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     if (ev) HIP_TRY(hipEventRecord(ev->e1, st));
 
     crag::MergeParams mp;
-    mp.partial = (const uint2 *)ix->partial.p;
+    mp.partial = (const uint2 *)ws->partial.p;
     mp.ids = ix->ids;
-    mp.gbound = (uint32_t *)ix->gbound.p;
+    mp.gbound = (uint32_t *)ws->gbound.p;
     mp.id_base = 0;
     mp.out_ids = d_out_ids;
     mp.out_scores = d_out_scores;
@@ -298,9 +318,11 @@ int crag_index_destroy(crag_index *ix) {
     if (ix->corpus) (void)hipFree(ix->corpus);
     if (ix->inv_norm) (void)hipFree(ix->inv_norm);
     if (ix->ids) (void)hipFree(ix->ids);
-    ix->qtiles.release();
-    ix->partial.release();
-    ix->gbound.release();
+    for (auto &w : ix->ws) {
+        w.qtiles.release();
+        w.partial.release();
+        w.gbound.release();
+    }
     ix->stage_q.release();
     ix->stage_rows.release();
     ix->stage_ids.release();
