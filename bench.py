@@ -238,9 +238,9 @@ def main() -> None:
         mfma_bound = nq > 32 and k <= 32
         traffic = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-        if os.path.exists(tpath) and rows == ROWS_PER_GPU and nq == QUERIES_PER_STEP:
-            try:
-                traffic = json.load(open(tpath)).get("scan_kernel_hbm_bytes_per_launch")
+        if os.path.exists(tpath) and rows == ROWS_PER_GPU and k == TOPK:
+            try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/traffic.json says how)
+                traffic = json.load(open(tpath))["by_queries_per_step"][str(nq)]["scan_kernel_hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         line = {
