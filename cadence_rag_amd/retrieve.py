@@ -36,6 +36,24 @@ class RetrieveFilters:
     call_tags: Optional[List[str]] = None
 
 
+def _resolve_call_ids(calls: Sequence[Dict[str, Any]], filters: Optional[RetrieveFilters]
+                      ) -> Optional[List[UUID]]:
+    """external_id (+ external_source) -> call ids, intersected with filters.call_ids
+    (/root/reference/app/retrieve.py:46-90).  `calls` stands in for the `calls` table: dicts with
+    call_id, external_id, external_source.  None means "no call scoping"; [] means "matches nothing"."""
+    if not filters:
+        return None
+    call_ids: Optional[Set[UUID]] = set(filters.call_ids) if filters.call_ids else None
+    if filters.external_id:
+        resolved = {c["call_id"] for c in calls
+                    if c.get("external_id") == filters.external_id
+                    and (filters.external_source is None or c.get("external_source") == filters.external_source)}
+        call_ids = (call_ids & resolved) if call_ids else resolved
+    if call_ids is None:
+        return None
+    return sorted(call_ids, key=str)
+
+
 def _rrf_merge(lanes: Dict[str, Sequence[Dict[str, Any]]], key_field: str, k: int = DEFAULT_RRF_K
                ) -> List[Tuple[Dict[str, Any], Set[str], float]]:
     """Reciprocal-rank fusion: score += 1/(k + rank), rank from 1; the first row seen for a key is

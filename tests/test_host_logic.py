@@ -312,3 +312,51 @@ def test_update_embeddings_rejects_length_mismatch():
                 [embedding_pipeline.PendingRow(1, UUID(int=1), "x")], [])
     finally:
         embedding_pipeline.set_store(None)
+
+
+# ---- B8 auto-embed hook (reference tests/unit/test_ingest_fs.py:130-195, same five cases) ------------
+def test_auto_embed_hook_statuses(monkeypatch):
+    from types import SimpleNamespace
+    from cadence_rag_amd import ingest_hook
+    monkeypatch.setattr(ingest_hook.settings, "ingest_auto_embed_on_success", False)
+    assert ingest_hook._auto_embed_call_if_configured(uuid4()) == {"status": "skipped", "reason": "disabled"}
+    monkeypatch.setattr(ingest_hook.settings, "ingest_auto_embed_on_success", True)
+    monkeypatch.setattr(ingest_hook, "embeddings_enabled", lambda: False)
+    assert ingest_hook._auto_embed_call_if_configured(uuid4()) == {"status": "skipped",
+                                                                     "reason": "embeddings_not_configured"}
+    monkeypatch.setattr(ingest_hook, "embeddings_enabled", lambda: True)
+    monkeypatch.setattr(ingest_hook.settings, "ingest_auto_embed_fail_on_error", False)
+    summary = SimpleNamespace(rows_updated=7, calls_touched=1, ingestion_runs_inserted=1,
+                              model_used="Qwen/Qwen3-Embedding-4B", per_table={"chunks": 4, "artifact_chunks": 3})
+    seen = {}
+    monkeypatch.setattr(ingest_hook, "run_embedding_backfill", lambda **kw: seen.update(kw) or summary)
+    cid = uuid4()
+    res = ingest_hook._auto_embed_call_if_configured(cid)
+    assert res == {"status": "ok", "rows_updated": 7, "calls_touched": 1, "model_used": "Qwen/Qwen3-Embedding-4B",
+                   "ingestion_runs_inserted": 1}
+    assert seen["call_id"] == cid and seen["source"] == "ingest_auto_embed" and seen["batch_size"] >= 1
+
+    def boom(**kw):
+        raise EmbeddingClientError("service timeout")
+
+    monkeypatch.setattr(ingest_hook, "run_embedding_backfill", boom)
+    res = ingest_hook._auto_embed_call_if_configured(uuid4())
+    assert res["status"] == "error" and "service timeout" in res["error"]
+    monkeypatch.setattr(ingest_hook.settings, "ingest_auto_embed_fail_on_error", True)
+    with pytest.raises(EmbeddingClientError):
+        ingest_hook._auto_embed_call_if_configured(uuid4())
+
+
+# ---- S7 _resolve_call_ids ---------------------------------------------------------------------------
+def test_resolve_call_ids_semantics():
+    a, b, c = UUID(int=1), UUID(int=2), UUID(int=3)
+    calls = [{"call_id": a, "external_id": "X", "external_source": "crm"},
+             {"call_id": b, "external_id": "X", "external_source": None},
+             {"call_id": c, "external_id": "Y", "external_source": "crm"}]
+    assert rt._resolve_call_ids(calls, None) is None
+    assert rt._resolve_call_ids(calls, rt.RetrieveFilters()) is None
+    assert rt._resolve_call_ids(calls, rt.RetrieveFilters(call_ids=[c, a])) == sorted([a, c], key=str)
+    assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="X")) == sorted([a, b], key=str)
+    assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="X", external_source="crm")) == [a]
+    assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="X", call_ids=[b, c])) == [b]
+    assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="nope")) == []
