@@ -152,30 +152,34 @@ def main() -> None:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; a rehearsal on a box with fewer GPUs than ranks folds ranks onto the GPUs it has
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist  # type: ignore
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CRAG_BENCH_BACKEND", "nccl")  # "gloo" only for rehearsals on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    from cadence_rag_amd.dense_index import DenseIndex, merge_topk
+    from cadence_rag_amd.dense_index import DenseIndex, ResultRecord, merge_topk_packed
 
     rows, nq, k = args.rows_per_gpu, args.queries, args.topk
     corpus = synth(rows, 1234 + rank, dev)
     queries = synth(max(nq, 64), 4321, dev)[:nq].contiguous()  # same queries on every rank
     ids = torch.arange(rank * rows, (rank + 1) * rows, dtype=torch.int64, device=dev)
-    index = DenseIndex(DIM, capacity=rows, device=local_rank)
+    index = DenseIndex(DIM, capacity=rows, device=dev_index)
     index.add(corpus, ids)
 
-    out_ids = torch.empty(nq, k, dtype=torch.int64, device=dev)
-    out_sc = torch.empty(nq, k, dtype=torch.float32, device=dev)
-    out_ct = torch.empty(nq, dtype=torch.int32, device=dev)
+    rec = ResultRecord(nq, k, dev)  # the search writes straight into the record that gets all-gathered
+    out_ids, out_sc, out_ct = rec.ids, rec.scores, rec.counts
     if world > 1:
-        g_ids = torch.empty(world * nq, k, dtype=torch.int64, device=dev)
-        g_sc = torch.empty(world * nq, k, dtype=torch.float32, device=dev)
-        g_ct = torch.empty(world * nq, dtype=torch.int32, device=dev)
+        gathered = torch.empty(world * rec.nbytes, dtype=torch.uint8, device=dev)
         f_ids = torch.empty_like(out_ids)
         f_sc = torch.empty_like(out_sc)
         f_ct = torch.empty_like(out_ct)
@@ -183,7 +187,8 @@ def main() -> None:
     stream = torch.cuda.current_stream().cuda_stream
     extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1) - 1)] if world == 1 else []
     lanes = [(stream, out_ids, out_sc, out_ct)] + [
-        (s.cuda_stream, torch.empty_like(out_ids), torch.empty_like(out_sc), torch.empty_like(out_ct))
+        (s.cuda_stream, torch.empty(nq, k, dtype=torch.int64, device=dev),
+         torch.empty(nq, k, dtype=torch.float32, device=dev), torch.empty(nq, dtype=torch.int32, device=dev))
         for s in extra_streams]
     counter = [0]
 
@@ -194,12 +199,9 @@ def main() -> None:
             index.search_async(queries, k, oi_, os_, oc_, stream=st_)
             return
         index.search_async(queries, k, out_ids, out_sc, out_ct, stream=stream)
-        if world > 1:  # the path's one exchange step: 12*Q*k bytes per rank over xGMI
-            dist.all_gather_into_tensor(g_ids, out_ids)
-            dist.all_gather_into_tensor(g_sc, out_sc)
-            dist.all_gather_into_tensor(g_ct, out_ct)
-            merge_topk(g_ids.view(world, nq, k), g_sc.view(world, nq, k), g_ct.view(world, nq),
-                       f_ids, f_sc, f_ct, stream=stream)
+        if world > 1:  # the path's one exchange step: ONE all-gather of 12*Q*k + 4*Q bytes per rank over xGMI
+            dist.all_gather_into_tensor(gathered, rec.buf)
+            merge_topk_packed(gathered, world, nq, k, f_ids, f_sc, f_ct, stream=stream)
 
     def fence() -> None:
         if world > 1:

@@ -541,6 +541,43 @@ int crag_merge_topk(int device, const int64_t *d_ids, const float *d_scores, con
     p.out_ids = d_out_ids;
     p.out_scores = d_out_scores;
     p.out_counts = d_out_counts;
+    p.stride_ids = (int64_t)nq * k;
+    p.stride_scores = (int64_t)nq * k;
+    p.stride_counts = nq;
+    p.n_lists = n_lists;
+    p.nq = nq;
+    p.k = k;
+    HIP_TRY(crag::launch_merge_results(p, (hipStream_t)stream));
+    return CRAG_OK;
+}
+
+int64_t crag_result_record_bytes(int nq, int k) {
+    if (nq < 0 || k <= 0) return -1;
+    const int64_t b = (int64_t)nq * k * 8 + (int64_t)nq * k * 4 + (int64_t)nq * 4;
+    return (b + 7) & ~(int64_t)7;
+}
+
+int crag_merge_topk_packed(int device, const void *d_records, int n_lists, int nq, int k, int64_t *d_out_ids,
+                           float *d_out_scores, int32_t *d_out_counts, void *stream) {
+    if (!d_records || !d_out_ids || !d_out_scores || !d_out_counts) return fail(CRAG_EINVAL, "NULL pointer argument");
+    if (n_lists <= 0 || nq < 0 || k <= 0 || k > CRAG_MAX_K)
+        return fail(CRAG_EINVAL, "bad sizes n_lists=%d nq=%d k=%d", n_lists, nq, k);
+    if ((int64_t)n_lists * k > 4096) return fail(CRAG_EINVAL, "n_lists*k must be <= 4096");
+    if (nq == 0) return CRAG_OK;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(CRAG_EHIP, "hipSetDevice(%d) failed", device);
+    const int64_t rec = crag_result_record_bytes(nq, k);
+    const char *base = (const char *)d_records;
+    crag::XMergeParams p;
+    p.ids = (const int64_t *)base;
+    p.scores = (const float *)(base + (int64_t)nq * k * 8);
+    p.counts = (const int32_t *)(base + (int64_t)nq * k * 12);
+    p.out_ids = d_out_ids;
+    p.out_scores = d_out_scores;
+    p.out_counts = d_out_counts;
+    p.stride_ids = rec / 8;
+    p.stride_scores = rec / 4;
+    p.stride_counts = rec / 4;
     p.n_lists = n_lists;
     p.nq = nq;
     p.k = k;

@@ -52,6 +52,7 @@ struct XMergeParams {
     int64_t *out_ids;
     float *out_scores;
     int32_t *out_counts;
+    int64_t stride_ids, stride_scores, stride_counts;  // elements between consecutive lists
     int n_lists;
     int nq;
     int k;

@@ -1159,12 +1159,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_results_kernel(XMergePara
     __syncthreads();
     for (int e = tid; e < p.n_lists * k; e += MERGE_THREADS) {
         const int l = e / k, pos = e - l * k;
-        const int cnt = p.counts[(size_t)l * p.nq + q];
+        const int cnt = p.counts[(size_t)l * p.stride_counts + q];
         if (pos < cnt) {
-            const size_t src = ((size_t)l * p.nq + q) * k + pos;
+            const size_t src = (size_t)q * k + pos;
             const int idx = atomicAdd(&s_cnt, 1);
-            s_sc[idx] = f2ord(p.scores[src]);
-            s_id[idx] = p.ids[src];
+            s_sc[idx] = f2ord(p.scores[(size_t)l * p.stride_scores + src]);
+            s_id[idx] = p.ids[(size_t)l * p.stride_ids + src];
         }
     }
     __syncthreads();

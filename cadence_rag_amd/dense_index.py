@@ -206,3 +206,29 @@ def merge_topk(d_ids, d_scores, d_counts, d_out_ids, d_out_scores, d_out_counts,
                                       d_counts.data_ptr(), n_lists, nq, k, d_out_ids.data_ptr(),
                                       d_out_scores.data_ptr(), d_out_counts.data_ptr(),
                                       ctypes.c_void_p(stream)), "crag_merge_topk")
+
+
+class ResultRecord:
+    """One rank's search output packed for a single all-gather: a uint8 CUDA buffer with typed views
+    (ids int64 [nq,k], scores fp32 [nq,k], counts int32 [nq]) laid out as crag_merge_topk_packed
+    expects."""
+
+    def __init__(self, nq: int, k: int, device) -> None:
+        lib = _native.load()
+        self.nq, self.k = int(nq), int(k)
+        self.nbytes = int(lib.crag_result_record_bytes(self.nq, self.k))
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        a, b = self.nq * self.k * 8, self.nq * self.k * 12
+        self.ids = self.buf[:a].view(torch.int64).view(self.nq, self.k)
+        self.scores = self.buf[a:b].view(torch.float32).view(self.nq, self.k)
+        self.counts = self.buf[b:b + self.nq * 4].view(torch.int32)
+
+
+def merge_topk_packed(d_records, n_lists: int, nq: int, k: int, d_out_ids, d_out_scores, d_out_counts,
+                      stream: int = 0) -> None:
+    """Merge n_lists gathered ResultRecords (one contiguous uint8 CUDA tensor) into [nq, k]."""
+    lib = _native.load()
+    _native.check(lib.crag_merge_topk_packed(int(d_records.device.index or 0), d_records.data_ptr(), int(n_lists),
+                                             int(nq), int(k), d_out_ids.data_ptr(), d_out_scores.data_ptr(),
+                                             d_out_counts.data_ptr(), ctypes.c_void_p(stream)),
+                  "crag_merge_topk_packed")

@@ -11,7 +11,7 @@ from typing import Callable, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .dense_index import DenseIndex, merge_topk
+from .dense_index import DenseIndex, ResultRecord, merge_topk, merge_topk_packed
 
 
 def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
@@ -50,7 +50,29 @@ class ShardedSearch:
         merge_topk(g_ids, g_sc, g_ct, ids, sc, ct, stream=torch.cuda.current_stream().cuda_stream)
         return ids, sc, ct
 
+    def _search_packed(self, queries: torch.Tensor, k: int):
+        """HIP path: the search writes into a ResultRecord, ONE all-gather moves the records."""
+        nq = int(queries.shape[0])
+        world = dist.get_world_size(self.group)
+        key = (nq, k, world)
+        if getattr(self, "_packed_key", None) != key:
+            self._rec = ResultRecord(nq, k, queries.device)
+            self._gathered = torch.empty(world * self._rec.nbytes, dtype=torch.uint8, device=queries.device)
+            self._packed_key = key
+        rec = self._rec
+        stream = torch.cuda.current_stream().cuda_stream
+        self.index.search_async(queries, k, rec.ids, rec.scores, rec.counts, stream=stream)
+        dist.all_gather_into_tensor(self._gathered, rec.buf, group=self.group)
+        ids = torch.empty(nq, k, dtype=torch.int64, device=queries.device)
+        sc = torch.empty(nq, k, dtype=torch.float32, device=queries.device)
+        ct = torch.empty(nq, dtype=torch.int32, device=queries.device)
+        merge_topk_packed(self._gathered, world, nq, k, ids, sc, ct, stream=stream)
+        return ids, sc, ct
+
     def search(self, queries: torch.Tensor, k: int):
+        if (self.index is not None and self._local == self._hip_local and self._merge == self._hip_merge
+                and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return self._search_packed(queries, k)
         ids, sc, ct = self._local(queries, k)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:

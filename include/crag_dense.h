@@ -107,6 +107,14 @@ int crag_merge_topk(int device, const int64_t *d_ids, const float *d_scores,
                     const int32_t *d_counts, int n_lists, int nq, int k, int64_t *d_out_ids,
                     float *d_out_scores, int32_t *d_out_counts, void *stream);
 
+/* One-collective form of the exchange step.  A "result record" holds one rank's search output as
+ * [ids nq*k int64][scores nq*k fp32][counts nq int32], padded to a multiple of 8 bytes
+ * (crag_result_record_bytes).  Each rank lets crag_index_search_async write straight into its
+ * record, ONE all-gather moves the records, and this merges n_lists consecutive records. */
+int64_t crag_result_record_bytes(int nq, int k);
+int crag_merge_topk_packed(int device, const void *d_records, int n_lists, int nq, int k,
+                           int64_t *d_out_ids, float *d_out_scores, int32_t *d_out_counts, void *stream);
+
 /* Live kernel timing for bench.py's roofline: enabled = N > 0 records HIP events around the scan
  * (and merge) kernel of every N-th search, on the stream it is launched on (N = 1: every search;
  * larger N perturbs the timed region less); 0 disables.  crag_index_profile_read sums and clears

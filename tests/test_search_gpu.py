@@ -281,3 +281,30 @@ def test_dense_table_lane_rows_and_filters(gpu):
         assert rt._estimate_dense_candidates(table, "chunks", rt.RetrieveFilters(external_id="zz"), []) == 0
     finally:
         table.close()
+
+
+def test_packed_result_records_merge(gpu):
+    """The one-collective exchange form: two shards write into ResultRecords, the records are
+    concatenated as an all-gather would, crag_merge_topk_packed gives the unsharded answer."""
+    import torch
+    from cadence_rag_amd.dense_index import ResultRecord, merge_topk_packed
+    rng = np.random.default_rng(44)
+    corpus, q = unit_rows(rng, 7001), rng.standard_normal((5, 1024)).astype(np.float32)
+    k, dev = 7, torch.device("cuda", 0)
+    dq = torch.from_numpy(q).to(dev)
+    recs = []
+    for lo, hi in ((0, 3500), (3500, 7001)):
+        with DenseIndex(1024, capacity=hi - lo) as ix:
+            ix.add(corpus[lo:hi], ids=np.arange(lo, hi))
+            rec = ResultRecord(5, k, dev)
+            ix.search_async(dq, k, rec.ids, rec.scores, rec.counts, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            recs.append(rec.buf.clone())
+    gathered = torch.cat(recs)
+    oi = torch.empty(5, k, dtype=torch.int64, device=dev)
+    osc = torch.empty(5, k, dtype=torch.float32, device=dev)
+    oc = torch.empty(5, dtype=torch.int32, device=dev)
+    merge_topk_packed(gathered, 2, 5, k, oi, osc, oc)
+    torch.cuda.synchronize()
+    want = oracle.exact_topk(q, corpus, k, mode=oracle.F64)
+    assert_topk_matches(oi.cpu().numpy(), osc.cpu().numpy(), oc.cpu().numpy(), *want, tol=TOL)
