@@ -166,12 +166,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                     (long long)ix->size);
 
     crag::ScanParams sp;
-    sp.qtiles = nullptr;
-    if (wide) {
-        if ((rc = ws->qtiles.ensure((size_t)q_blocks * crag::TILE_FLOATS * sizeof(float)))) return rc;
-        HIP_TRY(crag::launch_prep_queries(d_queries, nq, ix->dim, (float *)ws->qtiles.p, q_blocks, st));
-        sp.qtiles = (const float *)ws->qtiles.p;
-    }
+    sp.wide = wide ? 1 : 0;
     sp.corpus = ix->corpus;
     sp.inv_norm = ix->inv_norm;
     sp.queries = d_queries;

@@ -17,7 +17,7 @@ struct ScanParams {
     const float *corpus;      // tile32 layout
     const float *inv_norm;    // [cap_rows] 1/||row||, 0 = never eligible
     const float *queries;     // [nq, dim] row-major fp32 (raw; normalised in-kernel)
-    const float *qtiles;      // non-NULL: normalised queries in tile32 layout -> 64-query kernel
+    int wide;                 // 1: the 64-queries-per-pass kernel (two query blocks per pass)
     const uint32_t *mask;     // nullable; 32 rows per word
     int64_t mask_stride_w;    // words between consecutive queries' masks (0 = shared)
     uint2 *partial;           // [q_blocks][G][32][k] keys

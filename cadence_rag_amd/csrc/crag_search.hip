@@ -353,6 +353,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     write_lists<S>(p, c, list);
 }
 
+// Few candidates (the common case once the thresholds have tightened): insert them one by one into the
+// sorted 32-entry half-wave list instead of running the 21-stage network.  Per round each half-wave
+// takes its first remaining candidate, ranks it against the list with a ballot + popcount, and the
+// tail of the list shifts down by one lane.  Data-dependent trip count (wave-uniform).
+constexpr int SPARSE_MAX = 3;  // use this path when no half-wave has more candidates than this
+
+__device__ __forceinline__ void sparse_insert(uint32_t &lh, uint32_t &ll, uint32_t kh, uint32_t kl, bool cand, int lane) {
+    const bool hi_half = (lane & 32) != 0;
+    const int pp = lane & 31;
+    for (;;) {
+        const uint64_t m = __ballot(cand);
+        if (m == 0ull) break;
+        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+        const int s0 = m0 ? __builtin_ctz(m0) : 0, s1 = m1 ? 32 + __builtin_ctz(m1) : 32;
+        const uint32_t ch0 = __builtin_amdgcn_readlane(kh, s0), cl0 = __builtin_amdgcn_readlane(kl, s0);
+        const uint32_t ch1 = __builtin_amdgcn_readlane(kh, s1), cl1 = __builtin_amdgcn_readlane(kl, s1);
+        const bool valid = hi_half ? (m1 != 0u) : (m0 != 0u);
+        const uint32_t ch = hi_half ? ch1 : ch0, cl = hi_half ? cl1 : cl0;
+        cand = cand && (lane != (hi_half ? s1 : s0));
+        const uint64_t g = __ballot(mk64(lh, ll) > mk64(ch, cl));  // entries that stay ahead of the candidate
+        const int pos = hi_half ? __popc((uint32_t)(g >> 32)) : __popc((uint32_t)g);
+        const uint32_t uh = (uint32_t)__shfl_up((int)lh, 1, 32), ul = (uint32_t)__shfl_up((int)ll, 1, 32);
+        if (valid && pp >= pos) {
+            lh = (pp == pos) ? ch : uh;
+            ll = (pp == pos) ? cl : ul;
+        }
+    }
+}
+
+// number of set bits of the fuller half of a wave mask
+__device__ __forceinline__ int max_half_popc(uint64_t m) {
+    const int a = __popc((uint32_t)m), b = __popc((uint32_t)(m >> 32));
+    return a > b ? a : b;
+}
+
 // ---- pipelined kernel (k <= 32): the split-K reduction and the top-k selection of tile t-1 are
 // cut into small ops (<= ~12 VALU each) and spread over the MFMA slots of tile t, so that the
 // matrix pipe never waits for the LDS round trip or the sorting network.  The queries are used
@@ -426,6 +461,23 @@ struct PipeState {
 
 constexpr int PIPE_OPS = 28;
 
+// after a list changed: refresh its k-th key and publish an improved head to the global bound
+__device__ __forceinline__ void pipe_commit(const ScanParams &p, const ScanCtx &c, PipeState &st) {
+    PipeSel &n = st.n;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint64_t t = st.list[e].kth(p.k, c.lane);
+        n.th[e] = (uint32_t)(t >> 32);
+        n.tl[e] = (uint32_t)t;
+        const uint32_t head = st.list[e].hi[0];
+        if ((c.lane & 31) == 0 && c.qok[e] && head > n.pub[e]) {
+            n.pub[e] = head;  // only when the head improved: ~ln(rows) times per list
+            (void)__hip_atomic_fetch_max(p.gbound + (size_t)(c.qb * 32 + c.qloc[e]) * GB_CELLS + (c.g % p.k), head,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // background op OP of the tile-(t-1) epilogue; placed after MFMA 2*OP of tile t
 template <int OP>
 __device__ __forceinline__ void pipe_bg(const ScanParams &p, const ScanCtx &c, float2 (*slab)[SCAN_WAVES][8][64],
@@ -454,10 +506,21 @@ __device__ __forceinline__ void pipe_bg(const ScanParams &p, const ScanCtx &c, f
         n.l[e] = ok ? pt.nrow : 0u;
     } else if constexpr (OP == 6) {
         // a key matters only if it beats this workgroup's k-th AND is not below the global bound
-        const bool beats = ((mk64(n.h[0], n.l[0]) > mk64(n.th[0], n.tl[0])) && (n.h[0] >= pt.tauh[0])) ||
-                           ((mk64(n.h[1], n.l[1]) > mk64(n.th[1], n.tl[1])) && (n.h[1] >= pt.tauh[1]));
-        n.active = __any(beats);
-        if (n.active) net_issue<SortStage<0>::X>(n);
+        const bool b0 = (mk64(n.h[0], n.l[0]) > mk64(n.th[0], n.tl[0])) && (n.h[0] >= pt.tauh[0]);
+        const bool b1 = (mk64(n.h[1], n.l[1]) > mk64(n.th[1], n.tl[1])) && (n.h[1] >= pt.tauh[1]);
+        const uint64_t m0 = __ballot(b0), m1 = __ballot(b1);
+        n.active = (m0 | m1) != 0ull;
+        if (n.active) {
+            const int c0 = max_half_popc(m0), c1 = max_half_popc(m1);
+            if ((c0 > c1 ? c0 : c1) <= SPARSE_MAX) {  // few candidates: insert them directly, skip the network
+                sparse_insert(st.list[0].hi[0], st.list[0].lo[0], n.h[0], n.l[0], b0, lane);
+                sparse_insert(st.list[1].hi[0], st.list[1].lo[0], n.h[1], n.l[1], b1, lane);
+                pipe_commit(p, c, st);
+                n.active = false;
+            } else {
+                net_issue<SortStage<0>::X>(n);
+            }
+        }
     } else if constexpr (OP >= 7 && OP <= 20) {  // consume sort stage OP-7, issue sort stage OP-6
         if (n.active) {
             net_consume<SortStage<OP - 7>::BIT>(n, lane);
@@ -490,16 +553,8 @@ __device__ __forceinline__ void pipe_bg(const ScanParams &p, const ScanCtx &c, f
             for (int e = 0; e < 2; ++e) {
                 st.list[e].hi[0] = n.h[e];
                 st.list[e].lo[0] = n.l[e];
-                const uint64_t t = st.list[e].kth(p.k, lane);
-                n.th[e] = (uint32_t)(t >> 32);
-                n.tl[e] = (uint32_t)t;
-                // publish this workgroup's best score of query e into its bucket (see gbound)
-                if ((lane & 31) == 0 && c.qok[e] && n.h[e] > n.pub[e]) {
-                    n.pub[e] = n.h[e];  // only when the head improved: ~ln(rows) times per list
-                    (void)__hip_atomic_fetch_max(p.gbound + (size_t)(c.qb * 32 + c.qloc[e]) * GB_CELLS + (c.g % p.k),
-                                                 n.h[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
             }
+            pipe_commit(p, c, st);
         }
     }
 }
@@ -673,24 +728,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     }
 }
 
-// ---- pipelined kernel for 64 queries per pass (k <= 32).  Intensity doubles (32 flop/B): the
-// pass is bound by the fp32 matrix pipe, not HBM.  Each wave multiplies every loaded B fragment
-// with TWO query blocks; the A fragments no longer fit in registers beside the selection state, so
-// they are streamed from L2 (the prepared, normalised tile32 copy of the queries) through an
-// 8-deep register ring exactly like B.  Reduction/selection ops of both query blocks are spread
-// over the 128 MFMA slots of the next tile. -----------------------------------------------------
-struct Pipe2Tile {
-    uint32_t nrow;
-    float scale[2][2];    // [query block][e]
-    uint32_t tauh[2][2];
-};
-
+// ---- pipelined kernel for 64 queries per pass (k <= 32).  Intensity doubles (32 flop/B): the pass
+// is bound by the fp32 matrix pipe, not HBM.  Each wave multiplies every loaded B fragment with TWO
+// query blocks whose A fragments both stay in registers (128 VGPRs); to make room, everything the
+// selection needs only occasionally (running lists, their k-th keys, per-tile scales and bounds)
+// lives in LDS, and the split-K slab is single-buffered (two barriers per tile). -----------------
 struct Pipe2State {
-    float2 rd[4];
+    float2 rd[4];           // partial sums being reduced
     float d[2];
-    HalfList<1> list[2][2];
-    uint32_t th[2][2], tl[2][2], pub[2][2];
-    PipeSel n;  // h/l/ph/pl/active are reused by the two query blocks one after the other
+    float sc[2];            // score scale of the two lists being processed (0 = not eligible)
+    uint32_t tb[2];         // global bound of their queries
+    uint32_t th[2], tl[2];  // their current k-th keys
+    uint32_t nrow;          // ~row of the tile whose partial sums sit in the slab
+    PipeSel n;
 };
 
 struct Pipe2Ctx {
@@ -699,40 +749,89 @@ struct Pipe2Ctx {
     int qglob[2][2];
 };
 
+struct Pipe2Lds {
+    float2 slab[SCAN_WAVES][2][8][64];          // 64 KiB split-K partial sums [producer][query block][pair][lane]
+    double red[SCAN_WAVES][2][32];              // partial sums of squares of the queries
+    uint2 list[SCAN_WAVES][2][2][64];           // running top-k lists (keys), one per owned query
+    uint2 tinfo[SCAN_WAVES][2][2][64];          // per (query, row): x = scale bits, y = global bound
+    uint2 kth[SCAN_WAVES][2][2][2];             // k-th key of every list, per half-wave
+    uint32_t pub[SCAN_WAVES][2][2][2];          // best score known to be in our global-bound bucket
+    float qinv[SCAN_WAVES][2][2][2];            // 1/||q|| of the owned queries
+};
+
+// store the two updated lists of query block QB, refresh their k-th keys, publish improved heads
+template <int QB>
+__device__ __forceinline__ void pipe2_commit(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx &c2, Pipe2Lds &L,
+                                             uint2 l0, uint2 l1) {
+    const int lane = c.lane;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint2 v = e == 0 ? l0 : l1;
+        L.list[c.w][QB][e][lane] = v;
+        const int ln = (p.k - 1) & 31;  // k-th key of each half, broadcast through LDS
+        if ((lane & 31) == ln) L.kth[c.w][QB][e][c.h] = v;
+        uint32_t *pub = &L.pub[c.w][QB][e][c.h];
+        if ((lane & 31) == 0 && c2.qok[QB][e] && v.x > *pub) {
+            *pub = v.x;  // publish only improvements over what our bucket is known to hold
+            (void)__hip_atomic_fetch_max(p.gbound + (size_t)c2.qglob[QB][e] * GB_CELLS + (c.g % p.k), v.x,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <int OP, int QB>
-__device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx &c2,
-                                         float2 (*slab)[SCAN_WAVES][2][8][64], int rbuf, const Pipe2Tile &pt,
+__device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx &c2, Pipe2Lds &L,
                                          Pipe2State &st) {
     const int lane = c.lane;
     PipeSel &n = st.n;
     if constexpr (OP == 0) {
-        if constexpr (QB == 0) __syncthreads();
-    } else if constexpr (OP == 1) {  // partial sums of producer waves 0..3
+        if constexpr (QB == 0) __syncthreads();  // every wave's partial accumulators of the previous tile are in the slab
+    } else if constexpr (OP == 1) {
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = slab[rbuf][ww][QB][c.w][lane];
-    } else if constexpr (OP == 2) {  // add them (fixed order) and fetch producers 4..7 into the same registers
+        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = L.slab[ww][QB][c.w][lane];
+    } else if constexpr (OP == 2) {  // fixed summation order: bit-reproducible
         st.d[0] = ((st.rd[0].x + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
         st.d[1] = ((st.rd[0].y + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = slab[rbuf][4 + ww][QB][c.w][lane];
+        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = L.slab[4 + ww][QB][c.w][lane];
     } else if constexpr (OP == 3) {
         st.d[0] = (((st.d[0] + st.rd[0].x) + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
         st.d[1] = (((st.d[1] + st.rd[0].y) + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint2 t = L.tinfo[c.w][QB][e][lane];
+            st.sc[e] = __uint_as_float(t.x);
+            st.tb[e] = t.y;
+            const uint2 kk = L.kth[c.w][QB][e][c.h];
+            st.th[e] = kk.x;
+            st.tl[e] = kk.y;
+        }
     } else if constexpr (OP == 4 || OP == 5) {
         constexpr int e = OP - 4;
-        float sc = st.d[e] * pt.scale[QB][e];
-        sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);
-        const bool ok = (pt.scale[QB][e] > 0.f) && (sc == sc);
+        float sc = st.d[e] * st.sc[e];
+        sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);  // pgvector clamps the similarity to [-1, 1]
+        const bool ok = (st.sc[e] > 0.f) && (sc == sc);
         const uint32_t u = __float_as_uint(sc);
         const uint32_t ord = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
         n.h[e] = ok ? ord : 0u;
-        n.l[e] = ok ? pt.nrow : 0u;
+        n.l[e] = ok ? st.nrow : 0u;
     } else if constexpr (OP == 6) {
-        const bool beats =
-            ((mk64(n.h[0], n.l[0]) > mk64(st.th[QB][0], st.tl[QB][0])) && (n.h[0] >= pt.tauh[QB][0])) ||
-            ((mk64(n.h[1], n.l[1]) > mk64(st.th[QB][1], st.tl[QB][1])) && (n.h[1] >= pt.tauh[QB][1]));
-        n.active = __any(beats);
-        if (n.active) net_issue<SortStage<0>::X>(n);
+        const bool b0 = (mk64(n.h[0], n.l[0]) > mk64(st.th[0], st.tl[0])) && (n.h[0] >= st.tb[0]);
+        const bool b1 = (mk64(n.h[1], n.l[1]) > mk64(st.th[1], st.tl[1])) && (n.h[1] >= st.tb[1]);
+        const uint64_t m0 = __ballot(b0), m1 = __ballot(b1);
+        n.active = (m0 | m1) != 0ull;
+        if (n.active) {
+            const int c0 = max_half_popc(m0), c1 = max_half_popc(m1);
+            if ((c0 > c1 ? c0 : c1) <= SPARSE_MAX) {  // few candidates: insert them directly, skip the network
+                uint2 l0 = L.list[c.w][QB][0][lane], l1 = L.list[c.w][QB][1][lane];
+                sparse_insert(l0.x, l0.y, n.h[0], n.l[0], b0, lane);
+                sparse_insert(l1.x, l1.y, n.h[1], n.l[1], b1, lane);
+                pipe2_commit<QB>(p, c, c2, L, l0, l1);
+                n.active = false;
+            } else {
+                net_issue<SortStage<0>::X>(n);
+            }
+        }
     } else if constexpr (OP >= 7 && OP <= 20) {
         if (n.active) {
             net_consume<SortStage<OP - 7>::BIT>(n, lane);
@@ -743,13 +842,14 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
             net_consume<SortStage<14>::BIT>(n, lane);
             net_issue<31>(n);
         }
-    } else if constexpr (OP == 22) {
+    } else if constexpr (OP == 22) {  // merge-split with the list: keep the elementwise max (bitonic)
         if (n.active) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const bool gt = mk64(n.ph[e], n.pl[e]) > mk64(st.list[QB][e].hi[0], st.list[QB][e].lo[0]);
-                n.h[e] = gt ? n.ph[e] : st.list[QB][e].hi[0];
-                n.l[e] = gt ? n.pl[e] : st.list[QB][e].lo[0];
+                const uint2 cur = L.list[c.w][QB][e][lane];
+                const bool gt = mk64(n.ph[e], n.pl[e]) > mk64(cur.x, cur.y);
+                n.h[e] = gt ? n.ph[e] : cur.x;
+                n.l[e] = gt ? n.pl[e] : cur.y;
             }
             net_issue<SortStage<16>::X>(n);
         }
@@ -761,26 +861,15 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
     } else if constexpr (OP == 27) {
         if (n.active) {
             net_consume<SortStage<20>::BIT>(n, lane);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                st.list[QB][e].hi[0] = n.h[e];
-                st.list[QB][e].lo[0] = n.l[e];
-                const uint64_t t = st.list[QB][e].kth(p.k, lane);
-                st.th[QB][e] = (uint32_t)(t >> 32);
-                st.tl[QB][e] = (uint32_t)t;
-                if ((lane & 31) == 0 && c2.qok[QB][e] && n.h[e] > st.pub[QB][e]) {
-                    st.pub[QB][e] = n.h[e];
-                    (void)__hip_atomic_fetch_max(p.gbound + (size_t)c2.qglob[QB][e] * GB_CELLS + (c.g % p.k), n.h[e],
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            pipe2_commit<QB>(p, c, c2, L, make_uint2(n.h[0], n.l[0]), make_uint2(n.h[1], n.l[1]));
         }
     }
 }
 
+template <int DBG>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) {
-    __shared__ float2 slab[2][SCAN_WAVES][2][8][64];  // 128 KiB
-    const ScanCtx c = make_ctx(p);                     // row range; its query fields are not used here
+    __shared__ Pipe2Lds L;
+    const ScanCtx c = make_ctx(p);  // row range; its query fields are not used here
     const int lane = c.lane, w = c.w, j = c.j;
     Pipe2Ctx c2;
 #pragma unroll
@@ -789,55 +878,77 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
         c2.qloc[e] = (r & 3) + 8 * (r >> 2) + 4 * c.h;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            c2.qglob[qb][e] = (blockIdx.y * 2 + qb) * 32 + c2.qloc[e];
+            c2.qglob[qb][e] = ((int)blockIdx.y * 2 + qb) * 32 + c2.qloc[e];
             c2.qok[qb][e] = c2.qglob[qb][e] < p.nq;
         }
     }
     const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
-    const f32x4 *qa[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-        qa[qb] = reinterpret_cast<const f32x4 *>(p.qtiles + (size_t)(blockIdx.y * 2 + qb) * TILE_FLOATS + w * (KSLICE * 32)) + lane;
 
-    // rings: B (from HBM) 8 deep, slot s & 7 serves steps s and s + 8; A (from L2) 4 deep
+    const __amdgpu_buffer_rsrc_t gb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.gbound, 0, (int)((uint32_t)gridDim.y * 64u * GB_CELLS * 4u), 0x00020000);
+    // B ring: 8 deep, slot s & 7 serves steps s and s + 8
     u32x4 b[8];
-    f32x4 a[2][4];
     uint32_t vcur = tile_voff(c, 0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + s * 1024, 0, 0);
+
+    // A operand: raw queries of the two blocks, lane (i = lane&31, h) holds q[i][128w + 8s + 4h + 0..3];
+    // 1/||q|| is applied to the score later
+    f32x4 a[2][16];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a[0][s] = qa[0][s * 64];
-        a[1][s] = qa[1][s * 64];
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = ((int)blockIdx.y * 2 + qb) * 32 + j;
+        const bool have = qi < p.nq;
+        const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
+        double ss = 0.0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int col = w * KSLICE + 8 * s + 4 * c.h;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (have) {
+                if ((p.dim & 3) == 0) {
+                    if (col < p.dim) v = *reinterpret_cast<const f32x4 *>(qrow + col);
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
+                        if (col + cc < p.dim) v[cc] = qrow[col + cc];
+                }
+            }
+            a[qb][s] = v;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) ss += (double)v[cc] * (double)v[cc];
+        }
+        ss += __shfl_xor(ss, 32);
+        if (c.h == 0) L.red[w][qb][j] = ss;  // combined after the first barrier of the tile loop
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            L.list[w][qb][e][lane] = make_uint2(0u, 0u);
+            L.tinfo[w][qb][e][lane] = make_uint2(0u, 0u);  // "no previous tile": nothing eligible
+            if ((lane & 31) == 0) {
+                L.kth[w][qb][e][c.h] = make_uint2(0u, 0u);
+                L.pub[w][qb][e][c.h] = 0u;
+                L.qinv[w][qb][e][c.h] = 0.f;
+            }
+        }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
 
     Pipe2State st;
     st.n.active = false;
     st.d[0] = st.d[1] = 0.f;
+    st.nrow = 0u;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         st.n.h[e] = st.n.l[e] = st.n.ph[e] = st.n.pl[e] = st.n.th[e] = st.n.tl[e] = st.n.pub[e] = 0u;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            st.list[qb][e].clear();
-            st.th[qb][e] = st.tl[qb][e] = st.pub[qb][e] = 0u;
-        }
+        st.sc[e] = 0.f;
+        st.tb[e] = st.th[e] = st.tl[e] = 0u;
     }
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) st.rd[ww] = make_float2(0.f, 0.f);
-    Pipe2Tile prev;
-    prev.nrow = 0u;
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            prev.scale[qb][e] = 0.f;
-            prev.tauh[qb][e] = 0u;
-        }
+    uint32_t cur_nrow = 0u;
 
-    int wbuf = 0;
     for (int ti = 0; ti < c.n_tiles; ++ti) {
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
@@ -848,82 +959,104 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
             for (int e = 0; e < 2; ++e) mword[qb][e] = gbv[qb][e] = 0xffffffffu;
-        Pipe2Tile cur;
-        cur.nrow = ~(uint32_t)row;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                cur.scale[qb][e] = 0.f;
-                cur.tauh[qb][e] = 0u;
-            }
+        st.nrow = cur_nrow;  // the tile whose sums are in the slab
+        cur_nrow = ~(uint32_t)row;
 
         f32x16 acc[2];
         acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc[1] = acc[0];
         static_for<0, 128>([&](auto M) {
             constexpr int m = decltype(M)::value;
-            constexpr int s = m >> 3, cc = (m >> 1) & 3, qb = m & 1, slot = s & 7, aslot = s & 3;
-            acc[qb] = CRAG_MFMA(a[qb][aslot][cc], b[slot][cc], acc[qb]);
-            if constexpr ((m & 7) == 7) {  // slots fully consumed: refill B for step s + 8, A for step s + 4
-                if constexpr (s < 8) b[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + (s + 8) * 1024, 0, 0);
-                else b[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (s - 8) * 1024, 0, 0);
-                a[0][aslot] = qa[0][((s + 4) & 15) * 64];
-                a[1][aslot] = qa[1][((s + 4) & 15) * 64];
+            // MFMA order: groups of 16 = two steps x {8 MFMAs on block 0, then 8 on block 1}.  Switching the
+            // accumulator costs the matrix pipe ~15 cycles, so each accumulator is kept for runs of 8.
+            constexpr int grp = m >> 4, r16 = m & 15, qb = r16 >> 3, s = 2 * grp + ((r16 >> 2) & 1), cc = r16 & 3,
+                          slot = s & 7;
+            acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
+            if constexpr (r16 == 15 && !(DBG & 2)) {  // both ring slots of the group consumed: refill for steps +8
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    constexpr int base = 2 * grp;
+                    const int st2 = base + ds;
+                    if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + (st2 + 8) * 1024, 0, 0);
+                    else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (st2 - 8) * 1024, 0, 0);
+                }
             }
-            if constexpr ((m & 1) == 0) {
+            if constexpr ((m & 1) == 0 && !(DBG & 8)) {
                 constexpr int o = m >> 1;
-                if constexpr (o < PIPE_OPS) pipe2_bg<o, 0>(p, c, c2, slab, wbuf ^ 1, prev, st);
-                else if constexpr (o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, 1>(p, c, c2, slab, wbuf ^ 1, prev, st);
+                if constexpr (o < PIPE_OPS) pipe2_bg<o, 0>(p, c, c2, L, st);
+                else if constexpr (o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, 1>(p, c, c2, L, st);
             }
-            if constexpr (m == 64) {  // epilogue operands of this tile, consumed from slot 113 on
+            if constexpr (m == 3) {
+                // first tile only: the query norms (partials were written before barrier 0)
+                if (ti == 0) {
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            double tot = 0.0;
+#pragma unroll
+                            for (int ww = 0; ww < SCAN_WAVES; ++ww) tot += L.red[ww][q2][c2.qloc[e]];
+                            const bool ok = c2.qok[q2][e] && (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
+                            float qv = ok ? (float)(1.0 / sqrt(tot)) : 0.f;
+                            if (!(qv < 3.0e38f)) qv = 0.f;
+                            if ((lane & 31) == 0) L.qinv[w][q2][e][c.h] = qv;
+                        }
+                }
+            }
+            if constexpr (m == 2 * (PIPE_OPS + 4) + 1 && !(DBG & 8)) {
+                // every wave has finished reading the slab (op 3 of query block 1): second barrier of the tile,
+                // after which the accumulators of THIS tile may overwrite it
+                __syncthreads();
+            }
+            if constexpr (m == 81) {  // epilogue operands of this tile, consumed from slot 121 on
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         if (p.mask)
                             mword[q2][e] = p.mask[(size_t)(c2.qok[q2][e] ? c2.qglob[q2][e] : 0) * (size_t)p.mask_stride_w + tile];
-                        if (j < p.k && c2.qok[q2][e])
-                            gbv[q2][e] = __hip_atomic_load(p.gbound + (size_t)c2.qglob[q2][e] * GB_CELLS + j,
-                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (DBG & 16) gbv[q2][e] = 0u;  // experiment: no global bound at all
+                        if constexpr (!(DBG & 16)) {
+                            // plain cached load on purpose: a device-coherent (sc1) load of these hot lines is
+                            // slow and, loads returning in order, stalls the whole prefetch ring behind it.  A
+                            // stale value only prunes less; the streaming traffic evicts the line every few tiles.
+                            uint32_t off = (j < p.k && c2.qok[q2][e]) ? (uint32_t)(c2.qglob[q2][e] * GB_CELLS + j) * 4u : 0x80000000u;
+                            asm volatile("" : "+v"(off));  // opaque: the load must be re-issued every tile
+                            const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(gb_rsrc, off, 0, 0);
+                            gbv[q2][e] = (off == 0x80000000u) ? 0xffffffffu : v;
+                        }
                     }
             }
-            if constexpr (m == 113) {
+            // epilogue operands of THIS tile -> LDS, one list per odd slot 121..127 (the ops that still read the
+            // previous tile's entries finished at slot 2 * 2 * PIPE_OPS = 112)
+            if constexpr ((m & 1) == 1 && m >= 121) {
+                constexpr int idx = (m - 121) >> 1, q2 = idx >> 1, e = idx & 1;
                 const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_row > 0.f);
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e)
-                        cur.scale[q2][e] = (row_ok && c2.qok[q2][e] && ((mword[q2][e] >> j) & 1u)) ? inv_row : 0.f;
-            }
-            if constexpr (m == 115 || m == 117 || m == 119 || m == 121) {
-                constexpr int idx = (m - 115) >> 1, q2 = idx >> 1, e = idx & 1;
-                cur.tauh[q2][e] = half_min_u32(gbv[q2][e]);
-                const uint32_t mine = (uint32_t)__shfl((int)gbv[q2][e], (lane & 32) | (c.g % p.k));
-                st.pub[q2][e] = mine > st.pub[q2][e] ? mine : st.pub[q2][e];
+                const float scale = (row_ok && ((mword[q2][e] >> j) & 1u)) ? inv_row * L.qinv[w][q2][e][c.h] : 0.f;
+                const uint32_t tau = half_min_u32(gbv[q2][e]);
+                L.tinfo[w][q2][e][lane] = make_uint2(__float_as_uint(scale), tau);
+                if ((lane & 31) == (c.g % p.k)) atomicMax(&L.pub[w][q2][e][c.h], gbv[q2][e]);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr)
-                slab[wbuf][w][qb][pr][lane] = make_float2(acc[qb][2 * pr], acc[qb][2 * pr + 1]);
-        wbuf ^= 1;
-        prev = cur;
+            for (int pr = 0; pr < 8; ++pr) L.slab[w][qb][pr][lane] = make_float2(acc[qb][2 * pr], acc[qb][2 * pr + 1]);
         vcur = vnext;
     }
-    if (c.n_tiles > 0) {
-        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 0>(p, c, c2, slab, wbuf ^ 1, prev, st); });
-        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 1>(p, c, c2, slab, wbuf ^ 1, prev, st); });
+    st.nrow = cur_nrow;
+    if (c.n_tiles > 0) {  // drain: epilogue of the last tile
+        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 0>(p, c, c2, L, st); });
+        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 1>(p, c, c2, L, st); });
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (!c2.qok[qb][e]) continue;
-            uint2 *dst = p.partial + (((size_t)(blockIdx.y * 2 + qb) * p.G + c.g) * 32 + c2.qloc[e]) * (size_t)p.k;
-            if (j < p.k) dst[j] = make_uint2(st.list[qb][e].hi[0], st.list[qb][e].lo[0]);
+            uint2 *dst = p.partial + (((size_t)((int)blockIdx.y * 2 + qb) * p.G + c.g) * 32 + c2.qloc[e]) * (size_t)p.k;
+            if (j < p.k) dst[j] = L.list[w][qb][e][lane];
         }
 }
 
@@ -1301,9 +1434,14 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // ------------------------------------------------------------------------------------------
 hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st) {
     dim3 grid(p.G, q_blocks), block(SCAN_THREADS);
-    if (p.qtiles) {  // 64 queries per pass (q_blocks is even): the MFMA-bound kernel
+    if (p.wide) {  // 64 queries per pass (q_blocks is even): the MFMA-bound kernel
         dim3 grid2(p.G, q_blocks / 2);
-        hipLaunchKernelGGL(scan_pipe2_kernel, grid2, block, 0, st, p);
+        if (p.debug_mode == 2) hipLaunchKernelGGL(scan_pipe2_kernel<2>, grid2, block, 0, st, p);
+        else if (p.debug_mode == 8) hipLaunchKernelGGL(scan_pipe2_kernel<8>, grid2, block, 0, st, p);
+        else if (p.debug_mode == 10) hipLaunchKernelGGL(scan_pipe2_kernel<10>, grid2, block, 0, st, p);
+        else if (p.debug_mode == 26) hipLaunchKernelGGL(scan_pipe2_kernel<26>, grid2, block, 0, st, p);
+        else if (p.debug_mode == 16) hipLaunchKernelGGL(scan_pipe2_kernel<16>, grid2, block, 0, st, p);
+        else hipLaunchKernelGGL(scan_pipe2_kernel<0>, grid2, block, 0, st, p);
         return hipGetLastError();
     }
     if (p.k <= 32 && p.debug_mode == 2)
