@@ -1,0 +1,155 @@
+// crag_fusion.hip — reciprocal-rank fusion of retrieval lanes on the GPU (BASELINE configs[4]:
+// "dense top-100 fused with tech_tokens/BM25 lexical scores on GPU, batch = 64 queries").
+// Semantics of the reference's _rrf_merge (/root/reference/app/retrieve.py:245-260): for every key
+// score += 1/(k + rank) over the lanes in lane order (fp64, same summation order => bit-identical to
+// the Python floats), the first row seen for a key is kept, result sorted by score descending with
+// a STABLE sort, i.e. ties keep first-insertion order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/crag_dense.h"
+
+extern "C" void crag_set_error_(const char *msg);
+
+namespace {
+
+constexpr int FUSE_THREADS = 256;
+constexpr int FUSE_MAX_ITEMS = 1024;
+constexpr int FUSE_MAX_LANES = 8;
+
+struct FuseParams {
+    const int64_t *lane_ids[FUSE_MAX_LANES];    // [nq, width]
+    const int32_t *lane_counts[FUSE_MAX_LANES]; // [nq]
+    int width[FUSE_MAX_LANES];
+    int n_lanes, nq, rrf_k, out_k;
+    int64_t *out_ids;     // [nq, out_k]  -1 padded
+    double *out_scores;   // [nq, out_k]  NaN padded
+    uint32_t *out_lanes;  // [nq, out_k]  bit l set: lane l returned the key
+    int32_t *out_counts;  // [nq]
+};
+
+__global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
+    __shared__ int64_t key[FUSE_MAX_ITEMS];
+    __shared__ double term[FUSE_MAX_ITEMS];   // 1 / (k + rank) of the item
+    __shared__ double score[FUSE_MAX_ITEMS];  // valid at first-occurrence positions
+    __shared__ uint32_t lanes[FUSE_MAX_ITEMS];
+    __shared__ uint8_t lane_of[FUSE_MAX_ITEMS];
+    __shared__ int first[FUSE_MAX_ITEMS];     // first occurrence of the item's key
+    __shared__ int offs[FUSE_MAX_LANES + 1];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int o = 0;
+        for (int l = 0; l < p.n_lanes; ++l) {
+            offs[l] = o;
+            int c = p.lane_counts[l][q];
+            c = c < 0 ? 0 : (c > p.width[l] ? p.width[l] : c);
+            o += c;
+        }
+        offs[p.n_lanes] = o;
+    }
+    __syncthreads();
+    const int total = offs[p.n_lanes];
+    for (int l = 0; l < p.n_lanes; ++l) {
+        const int cnt = offs[l + 1] - offs[l];
+        for (int r = tid; r < cnt; r += FUSE_THREADS) {
+            const int i = offs[l] + r;
+            key[i] = p.lane_ids[l][(size_t)q * p.width[l] + r];
+            term[i] = 1.0 / (double)(p.rrf_k + r + 1);
+            lane_of[i] = (uint8_t)l;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += FUSE_THREADS) {
+        const int64_t k = key[i];
+        int f = i;
+        for (int jj = 0; jj < i; ++jj)
+            if (key[jj] == k) {
+                f = jj;
+                break;
+            }
+        first[i] = f;
+    }
+    __syncthreads();
+    for (int i = tid; i < total; i += FUSE_THREADS) {
+        if (first[i] != i) continue;
+        double s = 0.0;
+        uint32_t m = 0u;
+        for (int jj = i; jj < total; ++jj)  // insertion order = lane order, then rank: the reference's order
+            if (first[jj] == i) {
+                s += term[jj];
+                m |= 1u << lane_of[jj];
+            }
+        score[i] = s;
+        lanes[i] = m;
+    }
+    __syncthreads();
+    int n_unique = 0;
+    for (int i = tid; i < total; i += FUSE_THREADS) {
+        if (first[i] != i) continue;
+        const double s = score[i];
+        int rank = 0;
+        for (int jj = 0; jj < total; ++jj)
+            if (first[jj] == jj && (score[jj] > s || (score[jj] == s && jj < i))) ++rank;
+        if (rank < p.out_k) {
+            p.out_ids[(size_t)q * p.out_k + rank] = key[i];
+            p.out_scores[(size_t)q * p.out_k + rank] = s;
+            p.out_lanes[(size_t)q * p.out_k + rank] = lanes[i];
+        }
+    }
+    // unique count (serial over <= 1024 flags by one thread is fine at this size)
+    if (tid == 0) {
+        for (int i = 0; i < total; ++i) n_unique += (first[i] == i);
+        const int cnt = n_unique < p.out_k ? n_unique : p.out_k;
+        p.out_counts[q] = cnt;
+        for (int r = cnt; r < p.out_k; ++r) {
+            p.out_ids[(size_t)q * p.out_k + r] = -1;
+            p.out_scores[(size_t)q * p.out_k + r] = __longlong_as_double(0x7ff8000000000000ll);
+            p.out_lanes[(size_t)q * p.out_k + r] = 0u;
+        }
+    }
+}
+
+int ffail(const char *msg) {
+    crag_set_error_(msg);
+    return CRAG_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, const int32_t *const *d_lane_counts,
+                             const int *lane_width, int nq, int rrf_k, int out_k, int64_t *d_out_ids,
+                             double *d_out_scores, uint32_t *d_out_lanes, int32_t *d_out_counts, void *stream) {
+    if (n_lanes <= 0 || n_lanes > FUSE_MAX_LANES) return ffail("rrf_fuse: n_lanes must be in [1, 8]");
+    if (!d_lane_ids || !d_lane_counts || !lane_width || !d_out_ids || !d_out_scores || !d_out_lanes || !d_out_counts)
+        return ffail("rrf_fuse: NULL pointer");
+    if (nq < 0 || out_k <= 0 || rrf_k < 0) return ffail("rrf_fuse: bad sizes");
+    if (nq == 0) return CRAG_OK;
+    FuseParams p;
+    int total = 0;
+    for (int l = 0; l < n_lanes; ++l) {
+        if (!d_lane_ids[l] || !d_lane_counts[l] || lane_width[l] < 0) return ffail("rrf_fuse: bad lane");
+        p.lane_ids[l] = d_lane_ids[l];
+        p.lane_counts[l] = d_lane_counts[l];
+        p.width[l] = lane_width[l];
+        total += lane_width[l];
+    }
+    if (total > FUSE_MAX_ITEMS) return ffail("rrf_fuse: more than 1024 items per query");
+    p.n_lanes = n_lanes;
+    p.nq = nq;
+    p.rrf_k = rrf_k;
+    p.out_k = out_k;
+    p.out_ids = d_out_ids;
+    p.out_scores = d_out_scores;
+    p.out_lanes = d_out_lanes;
+    p.out_counts = d_out_counts;
+    hipLaunchKernelGGL(rrf_fuse_kernel, dim3((unsigned)nq), dim3(FUSE_THREADS), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "rrf_fuse launch failed: %s", hipGetErrorString(e));
+        crag_set_error_(buf);
+        return CRAG_EHIP;
+    }
+    return CRAG_OK;
+}

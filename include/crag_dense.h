@@ -115,6 +115,17 @@ int64_t crag_result_record_bytes(int nq, int k);
 int crag_merge_topk_packed(int device, const void *d_records, int n_lists, int nq, int k,
                            int64_t *d_out_ids, float *d_out_scores, int32_t *d_out_counts, void *stream);
 
+/* Reciprocal-rank fusion of up to 8 retrieval lanes on the GPU (hybrid /retrieve, BASELINE configs[4]).
+ * Replaces: _rrf_merge (retrieve.py:245-260) — score += 1/(rrf_k + rank) per lane in lane order (fp64,
+ * bit-identical to the Python floats), stable descending order (ties keep first-insertion order).
+ *   d_lane_ids[l]    device [nq, lane_width[l]] int64 keys of lane l, best first
+ *   d_lane_counts[l] device [nq] valid entries per query
+ *   outputs          [nq, out_k]: fused keys (-1 pad), fp64 scores (NaN pad), lane-hit bit masks; [nq] counts
+ * The pointer arrays themselves live on the HOST. */
+int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, const int32_t *const *d_lane_counts,
+                  const int *lane_width, int nq, int rrf_k, int out_k, int64_t *d_out_ids,
+                  double *d_out_scores, uint32_t *d_out_lanes, int32_t *d_out_counts, void *stream);
+
 /* Live kernel timing for bench.py's roofline: enabled = N > 0 records HIP events around the scan
  * (and merge) kernel of every N-th search, on the stream it is launched on (N = 1: every search;
  * larger N perturbs the timed region less); 0 disables.  crag_index_profile_read sums and clears

@@ -308,3 +308,44 @@ def test_packed_result_records_merge(gpu):
     torch.cuda.synchronize()
     want = oracle.exact_topk(q, corpus, k, mode=oracle.F64)
     assert_topk_matches(oi.cpu().numpy(), osc.cpu().numpy(), oc.cpu().numpy(), *want, tol=TOL)
+
+
+def test_gpu_rrf_fusion_matches_reference_rrf_merge(gpu):
+    """crag_rrf_fuse == _rrf_merge: the reference's golden cases (ties included) and random lanes."""
+    import json
+    import torch
+    from cadence_rag_amd.fusion import rrf_fuse
+    dev = torch.device("cuda", 0)
+    gold = json.loads((GOLD / "reference_host_logic.json").read_text())["rrf_merge"]
+    rng = np.random.default_rng(17)
+    cases = [[(name, ids) for name, ids in c["lanes"]] for c in gold]
+    for _ in range(20):  # bm25 50 / tech 50 / dense 100 shaped lanes with heavy overlap
+        pool = rng.permutation(300)
+        cases.append([("bm25", rng.choice(pool[:120], size=rng.integers(0, 51), replace=False).tolist()),
+                      ("tech_tokens", rng.choice(pool[:150], size=rng.integers(0, 51), replace=False).tolist()),
+                      ("dense", rng.choice(pool[:200], size=rng.integers(1, 101), replace=False).tolist())])
+    n_lanes = 3
+    widths = [max(max((len(dict(c).get(n, [])) for c in cases), default=1), 1) for n in ("bm25", "tech_tokens", "dense")]
+    lanes = []
+    for li, name in enumerate(("bm25", "tech_tokens", "dense")):
+        ids = np.full((len(cases), widths[li]), -7, dtype=np.int64)
+        cnt = np.zeros(len(cases), dtype=np.int32)
+        for q, c in enumerate(cases):
+            v = dict(c).get(name, [])
+            ids[q, :len(v)] = v
+            cnt[q] = len(v)
+        lanes.append((torch.from_numpy(ids).to(dev), torch.from_numpy(cnt).to(dev)))
+    out = rrf_fuse(lanes, out_k=256)
+    torch.cuda.synchronize()
+    ids, scores, masks, counts = (out[k].cpu().numpy() for k in ("ids", "scores", "lanes", "counts"))
+    names = ("bm25", "tech_tokens", "dense")
+    for q, c in enumerate(cases):
+        # the reference iterates lanes in dict order; a lane missing from a golden case is simply absent
+        lane_rows = {name: [{"id": i} for i in dict(c).get(name, [])] for name in names if name in dict(c)}
+        want = rt._rrf_merge(lane_rows, "id")
+        assert counts[q] == len(want)
+        assert ids[q, :counts[q]].tolist() == [w[0]["id"] for w in want]
+        assert scores[q, :counts[q]].tolist() == [w[2] for w in want]  # bit-identical fp64
+        for pos, w in enumerate(want):
+            assert {names[b] for b in range(n_lanes) if masks[q, pos] >> b & 1} == w[1]
+        assert np.all(ids[q, counts[q]:] == -1)
