@@ -153,3 +153,136 @@ extern "C" int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, cons
     }
     return CRAG_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Exact-token lane (`tech_tokens && :tokens ... ORDER BY call_started_at DESC, id ASC LIMIT k`,
+// /root/reference/app/retrieve.py:183-242) for a batch of queries.  Rows carry their technical tokens as
+// 64-bit hashes in CSR form; `order[r]` is the row at position r of the static order
+// (call_started_at DESC, id ASC), so "ORDER BY ... LIMIT k" = the first k matching positions.
+//   kernel 1: one thread per position r, token-set overlap against every query (query tokens in LDS),
+//             one wave ballot per query -> per-query bitmaps over positions (row mask applied here)
+//   kernel 2: per query, popcount prefix over the bitmap -> the first k set bits -> ids
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int TECH_MAX_Q = 64;
+constexpr int TECH_MAX_QTOK = 32;
+
+struct TechParams {
+    const int32_t *order;      // [n] row position by recency rank
+    const int64_t *row_ptr;    // [n+1]
+    const uint64_t *tok;       // [nnz] token hashes
+    const int64_t *ids;        // [n] external ids (nullable: position)
+    const uint64_t *qtok;      // [nq, TECH_MAX_QTOK]
+    const int32_t *qtok_n;     // [nq]
+    const uint32_t *mask;      // nullable row mask (bit per ROW position), shared or per query
+    int64_t mask_stride_w;
+    uint64_t *bitmap;          // [nq, words]
+    int64_t n, words;
+    int nq, k;
+    int64_t *out_ids;          // [nq, k]
+    int32_t *out_counts;       // [nq]
+};
+
+__global__ __launch_bounds__(256) void tech_match_kernel(TechParams p) {
+    __shared__ uint64_t s_qtok[TECH_MAX_Q][TECH_MAX_QTOK];
+    __shared__ int s_qn[TECH_MAX_Q];
+    for (int i = threadIdx.x; i < p.nq * TECH_MAX_QTOK; i += blockDim.x)
+        s_qtok[i / TECH_MAX_QTOK][i % TECH_MAX_QTOK] = p.qtok[i];
+    for (int i = threadIdx.x; i < p.nq; i += blockDim.x) s_qn[i] = p.qtok_n[i];
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // recency position
+    const bool live = r < p.n;
+    const int64_t row = live ? p.order[r] : 0;
+    const int64_t t0 = live ? p.row_ptr[row] : 0, t1 = live ? p.row_ptr[row + 1] : 0;
+    for (int q = 0; q < p.nq; ++q) {
+        bool hit = false;
+        if (live) {
+            bool eligible = true;
+            if (p.mask) eligible = (p.mask[(size_t)q * (size_t)p.mask_stride_w + (row >> 5)] >> (row & 31)) & 1u;
+            if (eligible)
+                for (int64_t t = t0; t < t1 && !hit; ++t) {
+                    const uint64_t h = p.tok[t];
+                    for (int i = 0; i < s_qn[q]; ++i) hit |= (s_qtok[q][i] == h);
+                }
+        }
+        const unsigned long long b = __ballot(hit);
+        if ((threadIdx.x & 63) == 0 && (r >> 6) < p.words) p.bitmap[(size_t)q * p.words + (r >> 6)] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void tech_select_kernel(TechParams p) {
+    __shared__ int s_cnt[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const uint64_t *bm = p.bitmap + (size_t)q * p.words;
+    const int64_t per = (p.words + 255) / 256;
+    const int64_t w0 = (int64_t)tid * per, w1 = (w0 + per < p.words) ? w0 + per : p.words;
+    int c = 0;
+    for (int64_t w = w0; w < w1; ++w) c += __popcll(bm[w]);
+    s_cnt[tid] = c;
+    __syncthreads();
+    int before = 0;
+    for (int i = 0; i < tid; ++i) before += s_cnt[i];  // 256 entries: fine
+    int total = 0;
+    if (tid == 0) {
+        for (int i = 0; i < 256; ++i) total += s_cnt[i];
+        const int cnt = total < p.k ? total : p.k;
+        p.out_counts[q] = cnt;
+        for (int i = cnt; i < p.k; ++i) p.out_ids[(size_t)q * p.k + i] = -1;
+    }
+    if (before < p.k) {
+        int pos = before;
+        for (int64_t w = w0; w < w1 && pos < p.k; ++w) {
+            uint64_t bits = bm[w];
+            while (bits && pos < p.k) {
+                const int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                const int64_t row = p.order[w * 64 + b];
+                p.out_ids[(size_t)q * p.k + pos] = p.ids ? p.ids[row] : row;
+                ++pos;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint64_t *d_tokens,
+                              const int64_t *d_ids, int64_t n_rows, const uint64_t *d_query_tokens,
+                              const int32_t *d_query_token_counts, int nq, int k, const uint8_t *d_row_mask,
+                              int64_t mask_stride, uint64_t *d_bitmap_scratch, int64_t *d_out_ids,
+                              int32_t *d_out_counts, void *stream) {
+    if (!d_order || !d_row_ptr || !d_tokens || !d_query_tokens || !d_query_token_counts || !d_bitmap_scratch ||
+        !d_out_ids || !d_out_counts)
+        return ffail("tech_lane: NULL pointer");
+    if (nq < 0 || nq > TECH_MAX_Q || k <= 0 || n_rows < 0) return ffail("tech_lane: need 0 <= nq <= 64, k > 0");
+    if (nq == 0) return CRAG_OK;
+    TechParams p;
+    p.order = d_order;
+    p.row_ptr = d_row_ptr;
+    p.tok = d_tokens;
+    p.ids = d_ids;
+    p.qtok = d_query_tokens;
+    p.qtok_n = d_query_token_counts;
+    p.mask = (const uint32_t *)d_row_mask;
+    p.mask_stride_w = mask_stride / 4;
+    p.bitmap = d_bitmap_scratch;
+    p.n = n_rows;
+    p.words = (n_rows + 63) / 64;
+    p.nq = nq;
+    p.k = k;
+    p.out_ids = d_out_ids;
+    p.out_counts = d_out_counts;
+    if (p.words == 0) p.words = 1;
+    const unsigned blocks = (unsigned)((p.words * 64 + 255) / 256);
+    hipLaunchKernelGGL(tech_match_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(tech_select_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "tech_lane launch failed: %s", hipGetErrorString(e));
+        crag_set_error_(buf);
+        return CRAG_EHIP;
+    }
+    return CRAG_OK;
+}

@@ -35,3 +35,66 @@ def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf
                                     out["scores"].data_ptr(), out["lanes"].data_ptr(), out["counts"].data_ptr(),
                                     ctypes.c_void_p(stream)), "crag_rrf_fuse")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# exact-token lane
+# ------------------------------------------------------------------------------------------------
+import hashlib  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+MAX_QUERY_TOKENS = 32
+
+
+def token_hash(token: str) -> int:
+    """64-bit hash of the EXACT token string (the SQL `&&` compares text[] elements exactly)."""
+    return int.from_bytes(hashlib.blake2b(token.encode("utf-8"), digest_size=8).digest(), "little")
+
+
+class TechTokenIndex:
+    """GPU-resident `tech_tokens text[]` column + the static order (call_started_at DESC, id ASC).
+    Counterpart of _fetch_chunks_tech / _fetch_artifacts_tech (/root/reference/app/retrieve.py:183-242)."""
+
+    def __init__(self, row_tokens, ids, call_started_at, device) -> None:
+        n = len(row_tokens)
+        ids = np.asarray(ids, dtype=np.int64)
+        ts = np.asarray(call_started_at, dtype="datetime64[us]").astype(np.int64)
+        order = np.lexsort((ids, -ts)).astype(np.int32)  # primary: started_at DESC, then id ASC
+        row_ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(t) for t in row_tokens], out=row_ptr[1:])
+        toks = np.array([token_hash(t) for row in row_tokens for t in row], dtype=np.uint64)
+        if toks.size == 0:
+            toks = np.zeros(1, dtype=np.uint64)
+        self.n = n
+        self.device = device
+        self.order = torch.from_numpy(order).to(device)
+        self.row_ptr = torch.from_numpy(row_ptr).to(device)
+        self.tokens = torch.from_numpy(toks.view(np.int64)).to(device)
+        self.ids = torch.from_numpy(ids).to(device)
+        self._bitmap = None
+
+    def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0):
+        """query_token_lists: per query the tokens of extract_tech_tokens(query) (at most 64 queries).
+        Returns (ids int64 [nq, k] -1 padded, counts int32 [nq]) CUDA tensors, best (most recent) first."""
+        nq = len(query_token_lists)
+        qt = np.zeros((nq, MAX_QUERY_TOKENS), dtype=np.uint64)
+        qn = np.zeros(nq, dtype=np.int32)
+        for i, toks in enumerate(query_token_lists):
+            toks = list(toks)[:MAX_QUERY_TOKENS]
+            qt[i, :len(toks)] = [token_hash(t) for t in toks]
+            qn[i] = len(toks)
+        d_qt = torch.from_numpy(qt.view(np.int64)).to(self.device)
+        d_qn = torch.from_numpy(qn).to(self.device)
+        words = max((self.n + 63) // 64, 1)
+        if self._bitmap is None or self._bitmap.numel() < nq * words:
+            self._bitmap = torch.empty(nq * words, dtype=torch.int64, device=self.device)
+        out_ids = torch.empty(nq, k, dtype=torch.int64, device=self.device)
+        out_ct = torch.empty(nq, dtype=torch.int32, device=self.device)
+        lib = _native.load()
+        _native.check(lib.crag_tech_lane(self.order.data_ptr(), self.row_ptr.data_ptr(), self.tokens.data_ptr(),
+                                         self.ids.data_ptr(), self.n, d_qt.data_ptr(), d_qn.data_ptr(), nq, int(k),
+                                         None if row_mask is None else row_mask.data_ptr(), int(mask_stride),
+                                         self._bitmap.data_ptr(), out_ids.data_ptr(), out_ct.data_ptr(),
+                                         ctypes.c_void_p(stream)), "crag_tech_lane")
+        return out_ids, out_ct

@@ -126,6 +126,21 @@ int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, const int32_t *
                   const int *lane_width, int nq, int rrf_k, int out_k, int64_t *d_out_ids,
                   double *d_out_scores, uint32_t *d_out_lanes, int32_t *d_out_counts, void *stream);
 
+/* Exact-token lane for a batch of up to 64 queries (hybrid /retrieve).  Replaces: _fetch_chunks_tech /
+ * _fetch_artifacts_tech (retrieve.py:183-242): rows whose token set overlaps the query's, first k in
+ * the order (call_started_at DESC, id ASC).  Tokens are 64-bit hashes of the exact token strings.
+ *   d_order [n] int32   row position at each rank of that static order
+ *   d_row_ptr [n+1] int64, d_tokens [nnz] uint64   CSR of the rows' token hashes
+ *   d_query_tokens [nq, 32] uint64, d_query_token_counts [nq] int32 (<= 32 tokens per query)
+ *   d_row_mask as in crag_index_search (bit per row POSITION; nullable)
+ *   d_bitmap_scratch [nq * ceil(n/64)] uint64
+ *   d_out_ids [nq, k] (-1 pad), d_out_counts [nq] */
+int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint64_t *d_tokens,
+                   const int64_t *d_ids, int64_t n_rows, const uint64_t *d_query_tokens,
+                   const int32_t *d_query_token_counts, int nq, int k, const uint8_t *d_row_mask,
+                   int64_t mask_stride, uint64_t *d_bitmap_scratch, int64_t *d_out_ids,
+                   int32_t *d_out_counts, void *stream);
+
 /* Live kernel timing for bench.py's roofline: enabled = N > 0 records HIP events around the scan
  * (and merge) kernel of every N-th search, on the stream it is launched on (N = 1: every search;
  * larger N perturbs the timed region less); 0 disables.  crag_index_profile_read sums and clears

@@ -349,3 +349,37 @@ def test_gpu_rrf_fusion_matches_reference_rrf_merge(gpu):
         for pos, w in enumerate(want):
             assert {names[b] for b in range(n_lanes) if masks[q, pos] >> b & 1} == w[1]
         assert np.all(ids[q, counts[q]:] == -1)
+
+
+def test_gpu_tech_token_lane_matches_sql_semantics(gpu):
+    """tech_tokens && :tokens ORDER BY call_started_at DESC, id ASC LIMIT k  (retrieve.py:183-242)."""
+    import torch
+    from cadence_rag_amd.fusion import TechTokenIndex
+    from cadence_rag_amd.tech_tokens import extract_tech_tokens
+    rng = np.random.default_rng(23)
+    vocab = ["ECONNRESET", "ABC-123", "v1.2.3", "HTTP 502", "BOM", "Dell", "vs", "10.25.0.50", "/etc/hosts", "Azure",
+             "econnreset"]  # exact match: case differs -> no overlap
+    n = 5000
+    row_tokens = [list(rng.choice(vocab, size=rng.integers(0, 4), replace=False)) for _ in range(n)]
+    ids = rng.permutation(n).astype(np.int64) + 1000
+    base = np.datetime64("2026-01-01T00:00:00", "us")
+    started = base + rng.integers(0, 50, size=n).astype("timedelta64[D]")  # many ties -> id ASC decides
+    dev = torch.device("cuda", 0)
+    index = TechTokenIndex(row_tokens, ids, started, dev)
+    queries = ["Where did we discuss ECONNRESET in api-gateway? ticket ABC-123 v1.2.3", "Dell vs Azure BOM",
+               "nothing technical here", "HTTP 502 from 10.25.0.50"]
+    qtoks = [extract_tech_tokens(q) for q in queries]
+    elig = rng.random(n) < 0.7
+    mask = torch.from_numpy(DenseIndex.pack_mask(elig)).to(dev)
+    for use_mask in (False, True):
+        out_ids, out_ct = index.search(qtoks, 50, row_mask=mask if use_mask else None)
+        torch.cuda.synchronize()
+        got_ids, got_ct = out_ids.cpu().numpy(), out_ct.cpu().numpy()
+        for qi, toks in enumerate(qtoks):
+            hits = [i for i in range(n) if set(toks) & set(row_tokens[i]) and (elig[i] or not use_mask)]
+            hits.sort(key=lambda i: (-started[i].astype(np.int64), ids[i]))
+            want = [int(ids[i]) for i in hits[:50]]
+            assert got_ct[qi] == len(want)
+            assert got_ids[qi, :len(want)].tolist() == want
+            assert np.all(got_ids[qi, len(want):] == -1)
+    assert qtoks[2] == [] and got_ct[2] == 0
