@@ -270,7 +270,7 @@ def main() -> None:
             } if mfma_bound else {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "crag::scan_pipe_kernel<0>" if k <= 32 else "crag::scan_kernel<S>",
+                "kernel": "crag::scan_pipe_kernel" if k <= 32 else "crag::scan_kernel<S>",
                 "kernel_avg_us": round(scan_avg_s * 1e6, 2),
                 "mfma_tflops": round(tflops, 1), "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFS, 4),
             }) | {

@@ -94,7 +94,7 @@ struct crag_index {
     struct Workspace {
         hipStream_t stream = nullptr;
         bool in_use = false;
-        DevBuf qtiles, partial, gbound;
+        DevBuf partial, gbound;
     } ws[MAX_WS];
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
@@ -183,12 +183,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     sp.reverse = ix->pass_parity;
     ix->pass_parity ^= 1;
     if (getenv("CRAG_NO_REVERSE")) sp.reverse = 0;
-    { const char *dm = getenv("CRAG_DEBUG_MODE"); sp.debug_mode = dm ? atoi(dm) : 0; }
-    sp.debug_out = nullptr;
-    if (sp.debug_mode == 64) {
-        if ((rc = ix->scratch.ensure(4096 * 4 * sizeof(unsigned long long)))) return rc;
-        sp.debug_out = (unsigned long long *)ix->scratch.p;
-    }
+    sp.unpipelined = getenv("CRAG_UNPIPELINED") ? 1 : 0;
 
     EvTriple *ev = nullptr;
     if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == 0) {
@@ -314,7 +309,6 @@ int crag_index_destroy(crag_index *ix) {
     if (ix->inv_norm) (void)hipFree(ix->inv_norm);
     if (ix->ids) (void)hipFree(ix->ids);
     for (auto &w : ix->ws) {
-        w.qtiles.release();
         w.partial.release();
         w.gbound.release();
     }
@@ -607,14 +601,6 @@ int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms
     if (scan_ms_total) *scan_ms_total = scan;
     if (merge_ms_total) *merge_ms_total = merge;
     ix->ev_used = 0;
-    return CRAG_OK;
-}
-
-int crag_debug_read_stamps(crag_index *ix, unsigned long long *out, int n_groups) {
-    if (!ix || !ix->scratch.p) return fail(CRAG_EINVAL, "no stamps");
-    DeviceGuard guard(ix->device);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, ix->scratch.p, (size_t)n_groups * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRAG_OK;
 }
 

@@ -29,8 +29,7 @@ struct ScanParams {
     int k;
     int G;
     int reverse;              // walk each workgroup's range back to front (alternates per search)
-    unsigned long long *debug_out;  // stamps (debug builds of the kernel only)
-    int debug_mode;           // 1: use the unpipelined kernel for k <= 32 (A/B testing)
+    int unpipelined;          // 1: use the unpipelined kernel also for k <= 32 (A/B testing, CRAG_UNPIPELINED=1)
 };
 
 struct MergeParams {
@@ -65,7 +64,6 @@ hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n,
                              float *inv_norm, hipStream_t st);
 hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
                             hipStream_t st);
-hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, int q_blocks, hipStream_t st);
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,
                                  unsigned long long *out, hipStream_t st);
 hipError_t launch_fill_ids(int64_t *ids, int64_t pos, int64_t n, int64_t first, hipStream_t st);

@@ -574,14 +574,11 @@ __device__ __forceinline__ uint32_t half_min_u32(uint32_t v) {
     return t < v ? t : v;
 }
 
-template <int DBG>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     __shared__ float2 slab[2][SCAN_WAVES][8][64];
     __shared__ double red[SCAN_WAVES][32];  // per-wave partial sums of squares of the 32 queries
     const ScanCtx c = make_ctx(p);
     const int lane = c.lane, w = c.w, j = c.j;
-    unsigned long long stampS = 0;
-    if constexpr (DBG & 64) stampS = __builtin_amdgcn_s_memrealtime();
 
     const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -627,8 +624,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     // iteration and drains the prefetch ring
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
-    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
-    if constexpr (DBG & 64) stamp1 = __builtin_amdgcn_s_memrealtime();
     PipeState st;
     st.list[0].clear();
     st.list[1].clear();
@@ -674,10 +669,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
         static_for<0, 64>([&](auto M) {
             constexpr int m = decltype(M)::value;
             constexpr int s = m >> 2, cc = m & 3;
-            if constexpr (!(DBG & 4)) acc = CRAG_MFMA(a[s][cc], b[s][cc], acc);
-            else acc[cc] += __uint_as_float(b[s][cc]);
-            if constexpr (cc == 3 && !(DBG & 2)) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
-            if constexpr ((m & 1) == 0 && (m >> 1) < PIPE_OPS && !(DBG & 8) && ((DBG >> 8) == 0 || (m >> 1) < (DBG >> 8))) {
+            acc = CRAG_MFMA(a[s][cc], b[s][cc], acc);
+            if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
+            if constexpr ((m & 1) == 0 && (m >> 1) < PIPE_OPS) {
                 pipe_bg<(m >> 1)>(p, c, slab, wbuf ^ 1, prev, st);
             }
             if constexpr (m == 5) {
@@ -714,18 +708,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
         wbuf ^= 1;
         prev = cur;
     }
-    if constexpr (DBG & 64) stamp2 = __builtin_amdgcn_s_memrealtime();
     if (c.n_tiles > 0) {  // drain: epilogue of the last tile
         static_for<0, PIPE_OPS>([&](auto O) { pipe_bg<decltype(O)::value>(p, c, slab, wbuf ^ 1, prev, st); });
     }
     write_lists<1>(p, c, st.list);
-    if constexpr (DBG & 64) {
-        stamp0 = __builtin_amdgcn_s_memrealtime();
-        if (threadIdx.x == 0 && p.debug_out) {
-            unsigned long long *o = p.debug_out + (size_t)blockIdx.x * 4;
-            o[0] = stampS; o[1] = stamp1; o[2] = stamp2; o[3] = stamp0;
-        }
-    }
 }
 
 // ---- pipelined kernel for 64 queries per pass (k <= 32).  Intensity doubles (32 flop/B): the pass
@@ -866,7 +852,6 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
     }
 }
 
-template <int DBG>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) {
     __shared__ Pipe2Lds L;
     const ScanCtx c = make_ctx(p);  // row range; its query fields are not used here
@@ -972,7 +957,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
             constexpr int grp = m >> 4, r16 = m & 15, qb = r16 >> 3, s = 2 * grp + ((r16 >> 2) & 1), cc = r16 & 3,
                           slot = s & 7;
             acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
-            if constexpr (r16 == 15 && !(DBG & 2)) {  // both ring slots of the group consumed: refill for steps +8
+            if constexpr (r16 == 15) {  // both ring slots of the group consumed: refill for steps +8
 #pragma unroll
                 for (int ds = 0; ds < 2; ++ds) {
                     constexpr int base = 2 * grp;
@@ -981,7 +966,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                     else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (st2 - 8) * 1024, 0, 0);
                 }
             }
-            if constexpr ((m & 1) == 0 && !(DBG & 8)) {
+            if constexpr ((m & 1) == 0) {
                 constexpr int o = m >> 1;
                 if constexpr (o < PIPE_OPS) pipe2_bg<o, 0>(p, c, c2, L, st);
                 else if constexpr (o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, 1>(p, c, c2, L, st);
@@ -1003,7 +988,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                         }
                 }
             }
-            if constexpr (m == 2 * (PIPE_OPS + 4) + 1 && !(DBG & 8)) {
+            if constexpr (m == 2 * (PIPE_OPS + 4) + 1) {
                 // every wave has finished reading the slab (op 3 of query block 1): second barrier of the tile,
                 // after which the accumulators of THIS tile may overwrite it
                 __syncthreads();
@@ -1015,8 +1000,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                     for (int e = 0; e < 2; ++e) {
                         if (p.mask)
                             mword[q2][e] = p.mask[(size_t)(c2.qok[q2][e] ? c2.qglob[q2][e] : 0) * (size_t)p.mask_stride_w + tile];
-                        if constexpr (DBG & 16) gbv[q2][e] = 0u;  // experiment: no global bound at all
-                        if constexpr (!(DBG & 16)) {
+                        {
                             // plain cached load on purpose: a device-coherent (sc1) load of these hot lines is
                             // slow and, loads returning in order, stalls the whole prefetch ring behind it.  A
                             // stale value only prunes less; the streaming traffic evicts the line every few tiles.
@@ -1379,37 +1363,6 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const float *corpus, int
         if (4 * kq + c < dim) dst[4 * kq + c] = v[c];
 }
 
-// queries [nq, dim] -> normalised, tile32 layout, zero-padded to a multiple of 32 queries.
-// A zero / non-finite query becomes all-NaN so that none of its scores is eligible.
-__global__ __launch_bounds__(256) void prep_queries_kernel(const float *queries, int nq, int dim,
-                                                           float *qtiles) {
-    __shared__ double sh[4];
-    const int qi = blockIdx.x;  // padded slot
-    const int kq = threadIdx.x;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (qi < nq) {
-        const float *src = queries + (size_t)qi * dim;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (4 * kq + c < dim) v[c] = src[4 * kq + c];
-    }
-    double ss = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
-    ss = block_sum_256(ss, sh);
-    if (qi < nq) {
-        const bool ok = (ss > 0.0) && (ss < 1.0e300) && (ss == ss);
-        if (ok) {
-            const double inv = 1.0 / sqrt(ss);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (float)((double)v[c] * inv);
-        } else {
-            const float nanv = __uint_as_float(0x7fc00000u);
-            v = f32x4{nanv, nanv, nanv, nanv};
-        }
-    }
-    float *dst = qtiles + (size_t)(qi >> 5) * TILE_FLOATS + ((size_t)kq * 32 + (qi & 31)) * 4;
-    *reinterpret_cast<f32x4 *>(dst) = v;
-}
-
 __global__ __launch_bounds__(256) void count_eligible_kernel(const float *inv_norm, int64_t n,
                                                              const uint32_t *mask,
                                                              unsigned long long *out) {
@@ -1434,44 +1387,17 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // ------------------------------------------------------------------------------------------
 hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st) {
     dim3 grid(p.G, q_blocks), block(SCAN_THREADS);
-    if (p.wide) {  // 64 queries per pass (q_blocks is even): the MFMA-bound kernel
-        dim3 grid2(p.G, q_blocks / 2);
-        if (p.debug_mode == 2) hipLaunchKernelGGL(scan_pipe2_kernel<2>, grid2, block, 0, st, p);
-        else if (p.debug_mode == 8) hipLaunchKernelGGL(scan_pipe2_kernel<8>, grid2, block, 0, st, p);
-        else if (p.debug_mode == 10) hipLaunchKernelGGL(scan_pipe2_kernel<10>, grid2, block, 0, st, p);
-        else if (p.debug_mode == 26) hipLaunchKernelGGL(scan_pipe2_kernel<26>, grid2, block, 0, st, p);
-        else if (p.debug_mode == 16) hipLaunchKernelGGL(scan_pipe2_kernel<16>, grid2, block, 0, st, p);
-        else hipLaunchKernelGGL(scan_pipe2_kernel<0>, grid2, block, 0, st, p);
-        return hipGetLastError();
-    }
-    if (p.k <= 32 && p.debug_mode == 2)
-        hipLaunchKernelGGL(scan_pipe_kernel<2>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 4)
-        hipLaunchKernelGGL(scan_pipe_kernel<4>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 10)
-        hipLaunchKernelGGL(scan_pipe_kernel<10>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 64)
-        hipLaunchKernelGGL(scan_pipe_kernel<64>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 258)
-        hipLaunchKernelGGL(scan_pipe_kernel<258>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 514)
-        hipLaunchKernelGGL(scan_pipe_kernel<514>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 1026)
-        hipLaunchKernelGGL(scan_pipe_kernel<1026>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 1538)
-        hipLaunchKernelGGL(scan_pipe_kernel<1538>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 1794)
-        hipLaunchKernelGGL(scan_pipe_kernel<1794>, grid, block, 0, st, p);
-    else if (p.k <= 32 && p.debug_mode == 8)
-        hipLaunchKernelGGL(scan_pipe_kernel<8>, grid, block, 0, st, p);
-    else if (p.k <= 32 && !p.debug_mode)
-        hipLaunchKernelGGL(scan_pipe_kernel<0>, grid, block, 0, st, p);
-    else if (p.k <= 32)
+    if (p.wide) {  // 64 queries per pass (q_blocks is even): the matrix-pipe-bound kernel
+        hipLaunchKernelGGL(scan_pipe2_kernel, dim3(p.G, q_blocks / 2), block, 0, st, p);
+    } else if (p.k <= 32 && !p.unpipelined) {
+        hipLaunchKernelGGL(scan_pipe_kernel, grid, block, 0, st, p);
+    } else if (p.k <= 32) {
         hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, st, p);
-    else if (p.k <= 64)
+    } else if (p.k <= 64) {
         hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, st, p);
-    else
+    } else {
         hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, st, p);
+    }
     return hipGetLastError();
 }
 
@@ -1497,12 +1423,6 @@ hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n
                             hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(load_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, corpus, dim, pos, rows);
-    return hipGetLastError();
-}
-
-hipError_t launch_prep_queries(const float *queries, int nq, int dim, float *qtiles, int q_blocks, hipStream_t st) {
-    const int slots = q_blocks * 32;
-    hipLaunchKernelGGL(prep_queries_kernel, dim3(slots), dim3(256), 0, st, queries, nq, dim, qtiles);
     return hipGetLastError();
 }
 

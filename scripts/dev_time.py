@@ -19,4 +19,4 @@ for _ in range(200): ix.search_async(q, k, oi, os_, oc, stream=st)
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 n, scan, merge = ix.profile_read()
-print(f"mode={os.environ.get('CRAG_DEBUG_MODE','0')} rows={rows} nq={nq} k={k}: step={el/200*1e6:.1f}us scan={scan/n*1e3:.1f}us merge={merge/n*1e3:.1f}us  scanBW={rows*4096/(scan/n*1e-3)/1e12:.2f}TB/s")
+print(f"mode={os.environ.get('CRAG_UNPIPELINED','0')} rows={rows} nq={nq} k={k}: step={el/200*1e6:.1f}us scan={scan/n*1e3:.1f}us merge={merge/n*1e3:.1f}us  scanBW={rows*4096/(scan/n*1e-3)/1e12:.2f}TB/s")
