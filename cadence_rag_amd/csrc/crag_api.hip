@@ -134,7 +134,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     if (nq <= 0) return CRAG_OK;
     int q_blocks = (nq + 31) / 32;
     // more than 32 queries and k <= 32: the 64-queries-per-pass kernel (two query blocks per pass)
-    const bool wide = (nq > 32) && (k <= 32) && !getenv("CRAG_NO_WIDE");
+    const bool wide = (nq > 32) && !getenv("CRAG_NO_WIDE");
     if (wide) q_blocks = ((nq + 63) / 64) * 2;
     const int G = scan_groups(ix);
     int rc;
@@ -180,6 +180,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     sp.nq = nq;
     sp.k = k;
     sp.G = G;
+    sp.nb = k < crag::GB_CELLS ? k : crag::GB_CELLS;
+    sp.pub_rank = (k + sp.nb - 1) / sp.nb - 1;
     sp.reverse = ix->pass_parity;
     ix->pass_parity ^= 1;
     if (getenv("CRAG_NO_REVERSE")) sp.reverse = 0;

@@ -28,6 +28,8 @@ struct ScanParams {
     int dim;
     int k;
     int G;
+    int nb;                   // global-bound buckets in use: min(k, GB_CELLS)
+    int pub_rank;             // rank (0-based) of the key a workgroup publishes: nb * (pub_rank + 1) >= k
     int reverse;              // walk each workgroup's range back to front (alternates per search)
     int unpipelined;          // 1: use the unpipelined kernel also for k <= 32 (A/B testing, CRAG_UNPIPELINED=1)
 };

@@ -714,11 +714,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     write_lists<1>(p, c, st.list);
 }
 
-// ---- pipelined kernel for 64 queries per pass (k <= 32).  Intensity doubles (32 flop/B): the pass
-// is bound by the fp32 matrix pipe, not HBM.  Each wave multiplies every loaded B fragment with TWO
-// query blocks whose A fragments both stay in registers (128 VGPRs); to make room, everything the
-// selection needs only occasionally (running lists, their k-th keys, per-tile scales and bounds)
-// lives in LDS, and the split-K slab is single-buffered (two barriers per tile). -----------------
+// ---- pipelined kernel family with the selection state in LDS: scan_pipe2_kernel<KS, NQB> ----------
+// NQB = 2: 64 queries per pass.  Intensity doubles (32 flop/B): the pass is bound by the fp32 matrix
+// pipe, not HBM.  Each wave multiplies every loaded B fragment with TWO query blocks whose A fragments
+// both stay in registers (128 VGPRs); to make room, everything the selection needs only occasionally
+// (running lists, their k-th keys, per-tile scales and bounds) lives in LDS, and the split-K slab is
+// single-buffered (two barriers per tile).
+// NQB = 1: 32 queries per pass with the same LDS-resident state (double-buffered slab, one barrier per
+// tile, 16-deep B ring): the HBM-bound pass for k > 32, which does not fit scan_pipe_kernel's registers.
+// KS = 1, 2, 4: list slots of 32 keys per query (k <= 32 * KS).  For KS > 1 the rare dense batches are
+// inserted inline (not spread over the MFMA slots), the common sparse ones one key at a time.
 struct Pipe2State {
     float2 rd[4];           // partial sums being reduced
     float d[2];
@@ -729,57 +734,134 @@ struct Pipe2State {
     PipeSel n;
 };
 
+template <int NQB>
 struct Pipe2Ctx {
     int qloc[2];
-    bool qok[2][2];
-    int qglob[2][2];
+    bool qok[NQB][2];
+    int qglob[NQB][2];
+    int bucket;    // this workgroup's global-bound bucket
 };
 
+template <int KS, int NQB>
 struct Pipe2Lds {
-    float2 slab[SCAN_WAVES][2][8][64];          // 64 KiB split-K partial sums [producer][query block][pair][lane]
-    double red[SCAN_WAVES][2][32];              // partial sums of squares of the queries
-    uint2 list[SCAN_WAVES][2][2][64];           // running top-k lists (keys), one per owned query
-    uint2 tinfo[SCAN_WAVES][2][2][64];          // per (query, row): x = scale bits, y = global bound
-    uint2 kth[SCAN_WAVES][2][2][2];             // k-th key of every list, per half-wave
-    uint32_t pub[SCAN_WAVES][2][2][2];          // best score known to be in our global-bound bucket
-    float qinv[SCAN_WAVES][2][2][2];            // 1/||q|| of the owned queries
+    float2 slab[3 - NQB][SCAN_WAVES][NQB][8][64];  // 64 KiB split-K partial sums [buf][producer][query block][pair][lane]
+    double red[SCAN_WAVES][NQB][32];               // partial sums of squares of the queries
+    uint2 list[SCAN_WAVES][NQB][2][KS][64];        // running top-k lists (keys), one per owned query
+    uint2 tinfo[SCAN_WAVES][NQB][2][64];           // per (query, row): x = scale bits, y = global bound
+    uint2 kth[SCAN_WAVES][NQB][2][2];              // k-th key of every list, per half-wave
+    uint32_t pub[SCAN_WAVES][NQB][2][2];           // best score known to be in our global-bound bucket
+    float qinv[SCAN_WAVES][NQB][2][2];             // 1/||q|| of the owned queries
 };
 
-// store the two updated lists of query block QB, refresh their k-th keys, publish improved heads
-template <int QB>
-__device__ __forceinline__ void pipe2_commit(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx &c2, Pipe2Lds &L,
-                                             uint2 l0, uint2 l1) {
+// Sparse insertion into a KS-slot list held in registers (position s*32 + lane&31, descending): per round
+// each half-wave takes its first remaining candidate, ranks it with ballots, and the tail shifts by one.
+template <int KS>
+__device__ __forceinline__ void sparse_insert_ks(HalfList<KS> &hl, uint32_t kh, uint32_t kl, bool cand, int lane) {
+    const bool hi_half = (lane & 32) != 0;
+    const int pp = lane & 31;
+    for (;;) {
+        const uint64_t m = __ballot(cand);
+        if (m == 0ull) break;
+        const uint32_t m0 = (uint32_t)m, m1 = (uint32_t)(m >> 32);
+        const int s0 = m0 ? __builtin_ctz(m0) : 0, s1 = m1 ? 32 + __builtin_ctz(m1) : 32;
+        const uint32_t ch0 = __builtin_amdgcn_readlane(kh, s0), cl0 = __builtin_amdgcn_readlane(kl, s0);
+        const uint32_t ch1 = __builtin_amdgcn_readlane(kh, s1), cl1 = __builtin_amdgcn_readlane(kl, s1);
+        const bool valid = hi_half ? (m1 != 0u) : (m0 != 0u);
+        const uint32_t ch = hi_half ? ch1 : ch0, cl = hi_half ? cl1 : cl0;
+        cand = cand && (lane != (hi_half ? s1 : s0));
+        int pos = 0;  // entries that stay ahead of the candidate
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const uint64_t g = __ballot(mk64(hl.hi[s], hl.lo[s]) > mk64(ch, cl));
+            pos += hi_half ? __popc((uint32_t)(g >> 32)) : __popc((uint32_t)g);
+        }
+        static_for<0, KS>([&](auto I) {  // back to front: the carry into slot s is the OLD tail of slot s-1
+            constexpr int s = KS - 1 - decltype(I)::value;
+            uint32_t uh = (uint32_t)__shfl_up((int)hl.hi[s], 1, 32), ul = (uint32_t)__shfl_up((int)hl.lo[s], 1, 32);
+            if constexpr (s > 0) {
+                const uint32_t th = (uint32_t)__shfl((int)hl.hi[s - 1], 31, 32), tl = (uint32_t)__shfl((int)hl.lo[s - 1], 31, 32);
+                uh = pp == 0 ? th : uh;
+                ul = pp == 0 ? tl : ul;
+            }
+            const int gp = s * 32 + pp;
+            if (valid && gp >= pos) {
+                hl.hi[s] = (gp == pos) ? ch : uh;
+                hl.lo[s] = (gp == pos) ? cl : ul;
+            }
+        });
+    }
+}
+
+// store the two updated lists of query block QB, refresh their k-th keys, publish improved bound keys
+template <int QB, int NQB, int KS>
+__device__ __forceinline__ void pipe2_commit(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx<NQB> &c2,
+                                             Pipe2Lds<KS, NQB> &L, uint2 l0, uint2 l1) {
     const int lane = c.lane;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const uint2 v = e == 0 ? l0 : l1;
-        L.list[c.w][QB][e][lane] = v;
+        L.list[c.w][QB][e][0][lane] = v;
         const int ln = (p.k - 1) & 31;  // k-th key of each half, broadcast through LDS
         if ((lane & 31) == ln) L.kth[c.w][QB][e][c.h] = v;
         uint32_t *pub = &L.pub[c.w][QB][e][c.h];
         if ((lane & 31) == 0 && c2.qok[QB][e] && v.x > *pub) {
             *pub = v.x;  // publish only improvements over what our bucket is known to hold
-            (void)__hip_atomic_fetch_max(p.gbound + (size_t)c2.qglob[QB][e] * GB_CELLS + (c.g % p.k), v.x,
+            (void)__hip_atomic_fetch_max(p.gbound + (size_t)c2.qglob[QB][e] * GB_CELLS + c2.bucket, v.x,
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-template <int OP, int QB>
-__device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx &c2, Pipe2Lds &L,
-                                         Pipe2State &st) {
+// KS > 1: one list (query block QB, owned query e) whose batch has candidates
+template <int QB, int NQB, int KS>
+__device__ __forceinline__ void pipe2_update_ks(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx<NQB> &c2,
+                                                Pipe2Lds<KS, NQB> &L, int e, uint32_t kh, uint32_t kl, bool cand,
+                                                int max_cnt) {
+    const int lane = c.lane;
+    HalfList<KS> hl;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const uint2 v = L.list[c.w][QB][e][s][lane];
+        hl.hi[s] = v.x;
+        hl.lo[s] = v.y;
+    }
+    if (max_cnt <= 2 * SPARSE_MAX) {
+        sparse_insert_ks<KS>(hl, kh, kl, cand, lane);
+    } else {
+        hl.insert(cand ? kh : 0u, cand ? kl : 0u, p.k, lane);
+    }
+    const int kslot = (p.k - 1) >> 5, ln = (p.k - 1) & 31;
+    uint2 kv = make_uint2(hl.hi[0], hl.lo[0]);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        L.list[c.w][QB][e][s][lane] = make_uint2(hl.hi[s], hl.lo[s]);
+        if (s == kslot) kv = make_uint2(hl.hi[s], hl.lo[s]);
+    }
+    if ((lane & 31) == ln) L.kth[c.w][QB][e][c.h] = kv;
+    // global bound for k > buckets: publish the key at rank pub_rank (< 32); buckets * (pub_rank + 1) >= k
+    uint32_t *pub = &L.pub[c.w][QB][e][c.h];
+    if ((lane & 31) == p.pub_rank && c2.qok[QB][e] && hl.hi[0] > *pub) {
+        *pub = hl.hi[0];
+        (void)__hip_atomic_fetch_max(p.gbound + (size_t)c2.qglob[QB][e] * GB_CELLS + c2.bucket, hl.hi[0],
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int OP, int QB, int NQB, int KS>
+__device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, const Pipe2Ctx<NQB> &c2,
+                                         Pipe2Lds<KS, NQB> &L, int rbuf, Pipe2State &st) {
     const int lane = c.lane;
     PipeSel &n = st.n;
     if constexpr (OP == 0) {
         if constexpr (QB == 0) __syncthreads();  // every wave's partial accumulators of the previous tile are in the slab
     } else if constexpr (OP == 1) {
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = L.slab[ww][QB][c.w][lane];
+        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = L.slab[rbuf][ww][QB][c.w][lane];
     } else if constexpr (OP == 2) {  // fixed summation order: bit-reproducible
         st.d[0] = ((st.rd[0].x + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
         st.d[1] = ((st.rd[0].y + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = L.slab[4 + ww][QB][c.w][lane];
+        for (int ww = 0; ww < 4; ++ww) st.rd[ww] = L.slab[rbuf][4 + ww][QB][c.w][lane];
     } else if constexpr (OP == 3) {
         st.d[0] = (((st.d[0] + st.rd[0].x) + st.rd[1].x) + st.rd[2].x) + st.rd[3].x;
         st.d[1] = (((st.d[1] + st.rd[0].y) + st.rd[1].y) + st.rd[2].y) + st.rd[3].y;
@@ -805,19 +887,27 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
         const bool b0 = (mk64(n.h[0], n.l[0]) > mk64(st.th[0], st.tl[0])) && (n.h[0] >= st.tb[0]);
         const bool b1 = (mk64(n.h[1], n.l[1]) > mk64(st.th[1], st.tl[1])) && (n.h[1] >= st.tb[1]);
         const uint64_t m0 = __ballot(b0), m1 = __ballot(b1);
-        n.active = (m0 | m1) != 0ull;
-        if (n.active) {
-            const int c0 = max_half_popc(m0), c1 = max_half_popc(m1);
-            if ((c0 > c1 ? c0 : c1) <= SPARSE_MAX) {  // few candidates: insert them directly, skip the network
-                uint2 l0 = L.list[c.w][QB][0][lane], l1 = L.list[c.w][QB][1][lane];
-                sparse_insert(l0.x, l0.y, n.h[0], n.l[0], b0, lane);
-                sparse_insert(l1.x, l1.y, n.h[1], n.l[1], b1, lane);
-                pipe2_commit<QB>(p, c, c2, L, l0, l1);
-                n.active = false;
-            } else {
-                net_issue<SortStage<0>::X>(n);
+        if constexpr (KS == 1) {
+            n.active = (m0 | m1) != 0ull;
+            if (n.active) {
+                const int c0 = max_half_popc(m0), c1 = max_half_popc(m1);
+                if ((c0 > c1 ? c0 : c1) <= SPARSE_MAX) {  // few candidates: insert them directly, skip the network
+                    uint2 l0 = L.list[c.w][QB][0][0][lane], l1 = L.list[c.w][QB][1][0][lane];
+                    sparse_insert(l0.x, l0.y, n.h[0], n.l[0], b0, lane);
+                    sparse_insert(l1.x, l1.y, n.h[1], n.l[1], b1, lane);
+                    pipe2_commit<QB, NQB, KS>(p, c, c2, L, l0, l1);
+                    n.active = false;
+                } else {
+                    net_issue<SortStage<0>::X>(n);
+                }
             }
+        } else {
+            n.active = false;  // the network ops stay idle: batches are handled here, inline
+            if (m0 != 0ull) pipe2_update_ks<QB, NQB, KS>(p, c, c2, L, 0, n.h[0], n.l[0], b0, max_half_popc(m0));
+            if (m1 != 0ull) pipe2_update_ks<QB, NQB, KS>(p, c, c2, L, 1, n.h[1], n.l[1], b1, max_half_popc(m1));
         }
+    } else if constexpr (KS > 1) {
+        // nothing: see OP 6
     } else if constexpr (OP >= 7 && OP <= 20) {
         if (n.active) {
             net_consume<SortStage<OP - 7>::BIT>(n, lane);
@@ -832,7 +922,7 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
         if (n.active) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const uint2 cur = L.list[c.w][QB][e][lane];
+                const uint2 cur = L.list[c.w][QB][e][0][lane];
                 const bool gt = mk64(n.ph[e], n.pl[e]) > mk64(cur.x, cur.y);
                 n.h[e] = gt ? n.ph[e] : cur.x;
                 n.l[e] = gt ? n.pl[e] : cur.y;
@@ -847,23 +937,27 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
     } else if constexpr (OP == 27) {
         if (n.active) {
             net_consume<SortStage<20>::BIT>(n, lane);
-            pipe2_commit<QB>(p, c, c2, L, make_uint2(n.h[0], n.l[0]), make_uint2(n.h[1], n.l[1]));
+            pipe2_commit<QB, NQB, KS>(p, c, c2, L, make_uint2(n.h[0], n.l[0]), make_uint2(n.h[1], n.l[1]));
         }
     }
 }
 
+template <int KS, int NQB>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) {
-    __shared__ Pipe2Lds L;
+    __shared__ Pipe2Lds<KS, NQB> L;
+    constexpr int RING = NQB == 2 ? 8 : 16;   // B prefetch ring depth (loads in flight per wave)
+    constexpr int SLOTS = 64 * NQB;           // MFMAs per tile and wave
     const ScanCtx c = make_ctx(p);  // row range; its query fields are not used here
     const int lane = c.lane, w = c.w, j = c.j;
-    Pipe2Ctx c2;
+    Pipe2Ctx<NQB> c2;
+    c2.bucket = c.g % p.nb;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int r = 2 * w + e;
         c2.qloc[e] = (r & 3) + 8 * (r >> 2) + 4 * c.h;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            c2.qglob[qb][e] = ((int)blockIdx.y * 2 + qb) * 32 + c2.qloc[e];
+        for (int qb = 0; qb < NQB; ++qb) {
+            c2.qglob[qb][e] = ((int)blockIdx.y * NQB + qb) * 32 + c2.qloc[e];
             c2.qok[qb][e] = c2.qglob[qb][e] < p.nq;
         }
     }
@@ -872,19 +966,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
         const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
 
     const __amdgpu_buffer_rsrc_t gb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.gbound, 0, (int)((uint32_t)gridDim.y * 64u * GB_CELLS * 4u), 0x00020000);
-    // B ring: 8 deep, slot s & 7 serves steps s and s + 8
-    u32x4 b[8];
+        p.gbound, 0, (int)((uint32_t)gridDim.y * (uint32_t)(NQB * 32) * GB_CELLS * 4u), 0x00020000);
+    // B ring: slot s % RING serves steps s and s + RING
+    u32x4 b[RING];
     uint32_t vcur = tile_voff(c, 0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + s * 1024, 0, 0);
+    for (int s = 0; s < RING; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + s * 1024, 0, 0);
 
-    // A operand: raw queries of the two blocks, lane (i = lane&31, h) holds q[i][128w + 8s + 4h + 0..3];
+    // A operand: raw queries of the block(s), lane (i = lane&31, h) holds q[i][128w + 8s + 4h + 0..3];
     // 1/||q|| is applied to the score later
-    f32x4 a[2][16];
+    f32x4 a[NQB][16];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qi = ((int)blockIdx.y * 2 + qb) * 32 + j;
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int qi = ((int)blockIdx.y * NQB + qb) * 32 + j;
         const bool have = qi < p.nq;
         const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
         double ss = 0.0;
@@ -909,7 +1003,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
         if (c.h == 0) L.red[w][qb][j] = ss;  // combined after the first barrier of the tile loop
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            L.list[w][qb][e][lane] = make_uint2(0u, 0u);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) L.list[w][qb][e][s][lane] = make_uint2(0u, 0u);
             L.tinfo[w][qb][e][lane] = make_uint2(0u, 0u);  // "no previous tile": nothing eligible
             if ((lane & 31) == 0) {
                 L.kth[w][qb][e][c.h] = make_uint2(0u, 0u);
@@ -933,49 +1028,63 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) st.rd[ww] = make_float2(0.f, 0.f);
     uint32_t cur_nrow = 0u;
+    int wbuf = 0;  // NQB == 1: slab buffer the tile now being multiplied is written to
+
+    // slot plan (NQB = 2 / 1): epilogue operands loaded at LOADS, written to LDS from TINFO on (odd slots),
+    // second barrier (single-buffered slab only) after op 3 of the last query block
+    constexpr int LOADS = NQB == 2 ? 81 : 41;
+    constexpr int TINFO = SLOTS - 1 - 2 * (2 * NQB - 1);  // 121 / 61
+    constexpr int BAR2 = 2 * (PIPE_OPS + 4) + 1;
 
     for (int ti = 0; ti < c.n_tiles; ++ti) {
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
         const float inv_row = p.inv_norm[row];
-        uint32_t mword[2][2], gbv[2][2];
+        uint32_t mword[NQB][2], gbv[NQB][2];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
             for (int e = 0; e < 2; ++e) mword[qb][e] = gbv[qb][e] = 0xffffffffu;
         st.nrow = cur_nrow;  // the tile whose sums are in the slab
         cur_nrow = ~(uint32_t)row;
+        const int rbuf = NQB == 2 ? 0 : (wbuf ^ 1);
 
-        f32x16 acc[2];
-        acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        acc[1] = acc[0];
-        static_for<0, 128>([&](auto M) {
-            constexpr int m = decltype(M)::value;
-            // MFMA order: groups of 16 = two steps x {8 MFMAs on block 0, then 8 on block 1}.  Switching the
-            // accumulator costs the matrix pipe ~15 cycles, so each accumulator is kept for runs of 8.
-            constexpr int grp = m >> 4, r16 = m & 15, qb = r16 >> 3, s = 2 * grp + ((r16 >> 2) & 1), cc = r16 & 3,
-                          slot = s & 7;
-            acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
-            if constexpr (r16 == 15) {  // both ring slots of the group consumed: refill for steps +8
+        f32x16 acc[NQB];
 #pragma unroll
-                for (int ds = 0; ds < 2; ++ds) {
-                    constexpr int base = 2 * grp;
-                    const int st2 = base + ds;
-                    if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + (st2 + 8) * 1024, 0, 0);
-                    else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (st2 - 8) * 1024, 0, 0);
+        for (int qb = 0; qb < NQB; ++qb) acc[qb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        static_for<0, SLOTS>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            if constexpr (NQB == 2) {
+                // MFMA order: groups of 16 = two steps x {8 MFMAs on block 0, then 8 on block 1}.  Switching the
+                // accumulator costs the matrix pipe ~15 cycles, so each accumulator is kept for runs of 8.
+                constexpr int grp = m >> 4, r16 = m & 15, qb = r16 >> 3, s = 2 * grp + ((r16 >> 2) & 1), cc = r16 & 3,
+                              slot = s & 7;
+                acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
+                if constexpr (r16 == 15) {  // both ring slots of the group consumed: refill for steps +8
+#pragma unroll
+                    for (int ds = 0; ds < 2; ++ds) {
+                        constexpr int base = 2 * grp;
+                        const int st2 = base + ds;
+                        if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + (st2 + 8) * 1024, 0, 0);
+                        else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (st2 - 8) * 1024, 0, 0);
+                    }
                 }
+            } else {
+                constexpr int s = m >> 2, cc = m & 3;
+                acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], acc[0]);
+                if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
             }
             if constexpr ((m & 1) == 0) {
                 constexpr int o = m >> 1;
-                if constexpr (o < PIPE_OPS) pipe2_bg<o, 0>(p, c, c2, L, st);
-                else if constexpr (o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, 1>(p, c, c2, L, st);
+                if constexpr (o < PIPE_OPS) pipe2_bg<o, 0, NQB, KS>(p, c, c2, L, rbuf, st);
+                else if constexpr (NQB == 2 && o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, NQB - 1, NQB, KS>(p, c, c2, L, rbuf, st);
             }
             if constexpr (m == 3) {
                 // first tile only: the query norms (partials were written before barrier 0)
                 if (ti == 0) {
 #pragma unroll
-                    for (int q2 = 0; q2 < 2; ++q2)
+                    for (int q2 = 0; q2 < NQB; ++q2)
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             double tot = 0.0;
@@ -988,14 +1097,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                         }
                 }
             }
-            if constexpr (m == 2 * (PIPE_OPS + 4) + 1) {
+            if constexpr (NQB == 2 && m == BAR2) {
                 // every wave has finished reading the slab (op 3 of query block 1): second barrier of the tile,
                 // after which the accumulators of THIS tile may overwrite it
                 __syncthreads();
             }
-            if constexpr (m == 81) {  // epilogue operands of this tile, consumed from slot 121 on
+            if constexpr (m == LOADS) {  // epilogue operands of this tile, consumed from slot TINFO on
 #pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2)
+                for (int q2 = 0; q2 < NQB; ++q2)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         if (p.mask)
@@ -1004,43 +1113,49 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                             // plain cached load on purpose: a device-coherent (sc1) load of these hot lines is
                             // slow and, loads returning in order, stalls the whole prefetch ring behind it.  A
                             // stale value only prunes less; the streaming traffic evicts the line every few tiles.
-                            uint32_t off = (j < p.k && c2.qok[q2][e]) ? (uint32_t)(c2.qglob[q2][e] * GB_CELLS + j) * 4u : 0x80000000u;
+                            uint32_t off = (j < p.nb && c2.qok[q2][e]) ? (uint32_t)(c2.qglob[q2][e] * GB_CELLS + j) * 4u : 0x80000000u;
                             asm volatile("" : "+v"(off));  // opaque: the load must be re-issued every tile
                             const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(gb_rsrc, off, 0, 0);
                             gbv[q2][e] = (off == 0x80000000u) ? 0xffffffffu : v;
                         }
                     }
             }
-            // epilogue operands of THIS tile -> LDS, one list per odd slot 121..127 (the ops that still read the
-            // previous tile's entries finished at slot 2 * 2 * PIPE_OPS = 112)
-            if constexpr ((m & 1) == 1 && m >= 121) {
-                constexpr int idx = (m - 121) >> 1, q2 = idx >> 1, e = idx & 1;
+            // epilogue operands of THIS tile -> LDS, one list per odd slot TINFO.. (the ops that still read the
+            // previous tile's entries finished long before)
+            if constexpr ((m & 1) == 1 && m >= TINFO) {
+                constexpr int idx = (m - TINFO) >> 1, q2 = idx >> 1, e = idx & 1;
                 const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_row > 0.f);
                 const float scale = (row_ok && ((mword[q2][e] >> j) & 1u)) ? inv_row * L.qinv[w][q2][e][c.h] : 0.f;
                 const uint32_t tau = half_min_u32(gbv[q2][e]);
                 L.tinfo[w][q2][e][lane] = make_uint2(__float_as_uint(scale), tau);
-                if ((lane & 31) == (c.g % p.k)) atomicMax(&L.pub[w][q2][e][c.h], gbv[q2][e]);
+                if ((lane & 31) == c2.bucket) atomicMax(&L.pub[w][q2][e][c.h], gbv[q2][e]);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
+        const int sbuf = NQB == 2 ? 0 : wbuf;
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) L.slab[w][qb][pr][lane] = make_float2(acc[qb][2 * pr], acc[qb][2 * pr + 1]);
+            for (int pr = 0; pr < 8; ++pr) L.slab[sbuf][w][qb][pr][lane] = make_float2(acc[qb][2 * pr], acc[qb][2 * pr + 1]);
+        wbuf ^= 1;
         vcur = vnext;
     }
     st.nrow = cur_nrow;
     if (c.n_tiles > 0) {  // drain: epilogue of the last tile
-        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 0>(p, c, c2, L, st); });
-        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 1>(p, c, c2, L, st); });
+        const int rbuf = NQB == 2 ? 0 : (wbuf ^ 1);
+        static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 0, NQB, KS>(p, c, c2, L, rbuf, st); });
+        if constexpr (NQB == 2)
+            static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, NQB - 1, NQB, KS>(p, c, c2, L, rbuf, st); });
     }
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             if (!c2.qok[qb][e]) continue;
-            uint2 *dst = p.partial + (((size_t)((int)blockIdx.y * 2 + qb) * p.G + c.g) * 32 + c2.qloc[e]) * (size_t)p.k;
-            if (j < p.k) dst[j] = L.list[w][qb][e][lane];
+            uint2 *dst = p.partial + (((size_t)((int)blockIdx.y * NQB + qb) * p.G + c.g) * 32 + c2.qloc[e]) * (size_t)p.k;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                if (s * 32 + j < p.k) dst[s * 32 + j] = L.list[w][qb][e][s][lane];
         }
 }
 
@@ -1387,16 +1502,22 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // ------------------------------------------------------------------------------------------
 hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st) {
     dim3 grid(p.G, q_blocks), block(SCAN_THREADS);
-    if (p.wide) {  // 64 queries per pass (q_blocks is even): the matrix-pipe-bound kernel
-        hipLaunchKernelGGL(scan_pipe2_kernel, dim3(p.G, q_blocks / 2), block, 0, st, p);
-    } else if (p.k <= 32 && !p.unpipelined) {
+    const int ks = p.k <= 32 ? 1 : (p.k <= 64 ? 2 : 4);
+    if (p.unpipelined) {  // A/B testing only
+        if (ks == 1) hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, st, p);
+        else if (ks == 2) hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, st, p);
+        else hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, st, p);
+    } else if (p.wide) {  // 64 queries per pass (q_blocks is even): the matrix-pipe-bound kernel
+        const dim3 g2(p.G, q_blocks / 2);
+        if (ks == 1) hipLaunchKernelGGL((scan_pipe2_kernel<1, 2>), g2, block, 0, st, p);
+        else if (ks == 2) hipLaunchKernelGGL((scan_pipe2_kernel<2, 2>), g2, block, 0, st, p);
+        else hipLaunchKernelGGL((scan_pipe2_kernel<4, 2>), g2, block, 0, st, p);
+    } else if (ks == 1) {
         hipLaunchKernelGGL(scan_pipe_kernel, grid, block, 0, st, p);
-    } else if (p.k <= 32) {
-        hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, st, p);
-    } else if (p.k <= 64) {
-        hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, st, p);
+    } else if (ks == 2) {
+        hipLaunchKernelGGL((scan_pipe2_kernel<2, 1>), grid, block, 0, st, p);
     } else {
-        hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, st, p);
+        hipLaunchKernelGGL((scan_pipe2_kernel<4, 1>), grid, block, 0, st, p);
     }
     return hipGetLastError();
 }

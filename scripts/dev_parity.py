@@ -52,3 +52,12 @@ if __name__ == "__main__" and not os.environ.get("CRAG_SKIP_MAIN"):
     ok2 &= run(5000, 40, 10, mask_frac=0.1)
     ok2 &= run(3000, 64, 20, dup=True)
     print("WIDE ALL OK" if ok2 else "WIDE FAILURES")
+    # k > 32: LDS-list kernels, 32 and 64 queries per pass
+    ok3 = True
+    for args in [(20000, 7, 50), (20000, 33, 50), (50000, 64, 100), (100000, 1, 128), (100000, 64, 128), (300, 33, 64),
+                 (5000, 40, 128), (40, 3, 100), (100000, 20, 33), (1000000, 64, 100)]:
+        ok3 &= run(*args)
+    ok3 &= run(5000, 40, 64, mask_frac=0.1)
+    ok3 &= run(5000, 9, 100, mask_frac=0.01)
+    ok3 &= run(3000, 64, 40, dup=True)
+    print("BIGK ALL OK" if ok3 else "BIGK FAILURES")

@@ -21,3 +21,9 @@ python scripts/pmc_summary.py stats gpurun_out/r01/stats gpurun_out/r01/kernel_s
 rm -rf gpurun_out/r01/pmc_fetch64 gpurun_out/r01/pmc_write64 gpurun_out/r01/pmc_fetch32 gpurun_out/r01/pmc_write32
 find gpurun_out/r01/stats -name "*kernel_trace.csv" -delete
 head -12 gpurun_out/r01/kernel_stats.csv
+# 1M-row single-GPU lines (north-star target: >= 70 % of the HBM roofline at 1M x 1024)
+python bench.py --rows-per-gpu 1000000 --queries 32 --steps 50 --warmup 5 --no-encode --no-cpu-baseline > gpurun_out/r01/bench_1m_q32.json 2>> gpurun_out/r01/bench.err
+python bench.py --rows-per-gpu 1000000 --queries 64 --steps 50 --warmup 5 --no-encode --no-cpu-baseline > gpurun_out/r01/bench_1m_q64.json 2>> gpurun_out/r01/bench.err
+cat gpurun_out/r01/bench_1m_q32.json gpurun_out/r01/bench_1m_q64.json
+python scripts/hybrid_bench.py > gpurun_out/r01/hybrid.json 2>> gpurun_out/r01/bench.err
+cat gpurun_out/r01/hybrid.json

@@ -35,5 +35,13 @@ for _ in range(3): out = step()
 torch.cuda.synchronize(); n = 20; t0 = time.perf_counter()
 for _ in range(n): out = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+def lane_ms(fn, n=10):
+    fn(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return round((time.perf_counter() - t) / n * 1e3, 3)
+split = {"dense_top100_ms": lane_ms(lambda: index.search_async(q, 100, d_ids, d_sc, d_ct, stream=st)),
+         "token_lane_top50_ms": lane_ms(lambda: tech.search(qtoks, 50, stream=st)),
+         "rrf_fuse_ms": lane_ms(lambda: rrf_fuse([(bm25_ids, bm25_ct), (t_ids0, t_ct0), (d_ids, d_ct)], out_k=200, stream=st))
+         if (globals().update(dict(zip(("t_ids0", "t_ct0"), tech.search(qtoks, 50, stream=st)))) is None) else None}
 print(json.dumps({"workload": f"hybrid retrieve, {rows} chunks, batch {nq}: dense top-100 + token lane top-50 + bm25 ranks (given) -> RRF",
-                  "ms_per_batch": round(dt * 1e3, 3), "queries_per_s": round(nq / dt, 1), "fused_counts_min": int(out['counts'].min())}))
+                  "ms_per_batch": round(dt * 1e3, 3), "queries_per_s": round(nq / dt, 1), "fused_counts_min": int(out['counts'].min()), "split": split}))

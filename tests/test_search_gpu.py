@@ -87,6 +87,28 @@ def test_row_masks(gpu, frac, per_query):
     _check(corpus, q, 10, mask=mask)
 
 
+@pytest.mark.parametrize("nq,k,frac", [(9, 100, 0.01), (40, 64, 0.1), (64, 128, 0.5), (33, 40, 0.002)])
+def test_row_masks_large_k(gpu, nq, k, frac):
+    """k > 32 runs the LDS-list kernels (32 / 64 queries per pass); sparse masks leave fewer than k rows."""
+    rng = np.random.default_rng(nq * 1000 + k)
+    corpus = unit_rows(rng, 6000)
+    q = rng.standard_normal((nq, 1024)).astype(np.float32)
+    mask = rng.random((nq, 6000)) < frac
+    _check(corpus, q, k, mask=mask)
+
+
+@pytest.mark.parametrize("nq,k", [(3, 40), (64, 100)])
+def test_exact_ties_large_k(gpu, nq, k):
+    rng = np.random.default_rng(5 + nq)
+    corpus = unit_rows(rng, 4000)
+    corpus[2000:2060] = corpus[7]  # 60 identical rows + the original
+    q = rng.standard_normal((nq, 1024)).astype(np.float32)
+    q[0] = corpus[7] * 3.0
+    ids, scores, counts = _check(corpus, q, k)
+    want = ([7] + list(range(2000, 2060)))[:k]
+    assert list(ids[0, :len(want)]) == want
+
+
 def test_exact_ties_break_by_ascending_position(gpu):
     rng = np.random.default_rng(3)
     corpus = unit_rows(rng, 3000)
