@@ -157,91 +157,137 @@ extern "C" int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, cons
 // ------------------------------------------------------------------------------------------------
 // Exact-token lane (`tech_tokens && :tokens ... ORDER BY call_started_at DESC, id ASC LIMIT k`,
 // /root/reference/app/retrieve.py:183-242) for a batch of queries.  Rows carry their technical tokens as
-// 64-bit hashes in CSR form; `order[r]` is the row at position r of the static order
-// (call_started_at DESC, id ASC), so "ORDER BY ... LIMIT k" = the first k matching positions.
-//   kernel 1: one thread per position r, token-set overlap against every query (query tokens in LDS),
-//             one wave ballot per query -> per-query bitmaps over positions (row mask applied here)
-//   kernel 2: per query, popcount prefix over the bitmap -> the first k set bits -> ids
+// 64-bit hashes in CSR form, STORED IN THE STATIC ORDER (call_started_at DESC, id ASC): CSR row r is the
+// row at rank r, `order[r]` its position in the tables (for the row mask and the external id), so
+// "ORDER BY ... LIMIT k" = the first k matching ranks and the scan streams through HBM coalesced.
+//   kernel 1: the distinct query tokens go into an LDS hash table token -> 64-bit set of the queries that
+//             contain it; one thread per rank looks its tokens up and ORs the sets; 64 ballots transpose
+//             the wave's 64 x 64 bit matrix into one bitmap word per query (layout [word][query], so the
+//             wave writes one contiguous line); the row mask is applied here
+//   kernel 2: per query, walk the bitmap in chunks of 16384 ranks (popcount prefix) until k bits are found
 // ------------------------------------------------------------------------------------------------
 namespace {
 
 constexpr int TECH_MAX_Q = 64;
 constexpr int TECH_MAX_QTOK = 32;
+constexpr int TECH_SLOTS = 4096;  // >= 2 * TECH_MAX_Q * TECH_MAX_QTOK: load factor <= 0.5
 
 struct TechParams {
-    const int32_t *order;      // [n] row position by recency rank
-    const int64_t *row_ptr;    // [n+1]
+    const int32_t *order;      // [n] table position of the row at rank r
+    const int64_t *row_ptr;    // [n+1] CSR over ranks
     const uint64_t *tok;       // [nnz] token hashes
-    const int64_t *ids;        // [n] external ids (nullable: position)
+    const int64_t *ids;        // [n] external ids by table position (nullable: position)
     const uint64_t *qtok;      // [nq, TECH_MAX_QTOK]
     const int32_t *qtok_n;     // [nq]
-    const uint32_t *mask;      // nullable row mask (bit per ROW position), shared or per query
+    const uint32_t *mask;      // nullable row mask (bit per table POSITION), shared or per query
     int64_t mask_stride_w;
-    uint64_t *bitmap;          // [nq, words]
+    uint64_t *bitmap;          // [words, nq]
     int64_t n, words;
     int nq, k;
     int64_t *out_ids;          // [nq, k]
     int32_t *out_counts;       // [nq]
 };
 
+__device__ __forceinline__ uint32_t tech_slot(uint64_t h) { return (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 52); }  // 12 bits
+
 __global__ __launch_bounds__(256) void tech_match_kernel(TechParams p) {
-    __shared__ uint64_t s_qtok[TECH_MAX_Q][TECH_MAX_QTOK];
-    __shared__ int s_qn[TECH_MAX_Q];
-    for (int i = threadIdx.x; i < p.nq * TECH_MAX_QTOK; i += blockDim.x)
-        s_qtok[i / TECH_MAX_QTOK][i % TECH_MAX_QTOK] = p.qtok[i];
-    for (int i = threadIdx.x; i < p.nq; i += blockDim.x) s_qn[i] = p.qtok_n[i];
+    __shared__ unsigned long long s_key[TECH_SLOTS];   // 0 = empty (hash 0 is folded onto 1)
+    __shared__ unsigned long long s_set[TECH_SLOTS];   // queries containing the token
+    for (int i = threadIdx.x; i < TECH_SLOTS; i += blockDim.x) {
+        s_key[i] = 0ull;
+        s_set[i] = 0ull;
+    }
     __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // recency position
-    const bool live = r < p.n;
-    const int64_t row = live ? p.order[r] : 0;
-    const int64_t t0 = live ? p.row_ptr[row] : 0, t1 = live ? p.row_ptr[row + 1] : 0;
-    for (int q = 0; q < p.nq; ++q) {
-        bool hit = false;
-        if (live) {
-            bool eligible = true;
-            if (p.mask) eligible = (p.mask[(size_t)q * (size_t)p.mask_stride_w + (row >> 5)] >> (row & 31)) & 1u;
-            if (eligible)
-                for (int64_t t = t0; t < t1 && !hit; ++t) {
-                    const uint64_t h = p.tok[t];
-                    for (int i = 0; i < s_qn[q]; ++i) hit |= (s_qtok[q][i] == h);
-                }
+    for (int i = threadIdx.x; i < p.nq * TECH_MAX_QTOK; i += blockDim.x) {
+        const int q = i / TECH_MAX_QTOK, t = i % TECH_MAX_QTOK;
+        if (t >= p.qtok_n[q]) continue;
+        uint64_t h = p.qtok[i];
+        h = h ? h : 1ull;
+        uint32_t sl = tech_slot(h);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&s_key[sl], 0ull, (unsigned long long)h);
+            if (old == 0ull || old == h) {
+                atomicOr(&s_set[sl], 1ull << q);
+                break;
+            }
+            sl = (sl + 1) & (TECH_SLOTS - 1);
         }
-        const unsigned long long b = __ballot(hit);
-        if ((threadIdx.x & 63) == 0 && (r >> 6) < p.words) p.bitmap[(size_t)q * p.words + (r >> 6)] = b;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // whole waves stay together: every lane of a wave runs the same number of rounds
+    for (int64_t r0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); r0 < p.words * 64; r0 += stride) {
+        const int64_t r = r0 + lane;
+        const bool live = r < p.n;
+        uint64_t qset = 0ull;
+        int64_t row = 0;
+        if (live) {
+            const int64_t t0 = p.row_ptr[r], t1 = p.row_ptr[r + 1];
+            for (int64_t t = t0; t < t1; ++t) {
+                uint64_t h = p.tok[t];
+                h = h ? h : 1ull;
+                uint32_t sl = tech_slot(h);
+                for (;;) {
+                    const unsigned long long kk = s_key[sl];
+                    if (kk == h) {
+                        qset |= s_set[sl];
+                        break;
+                    }
+                    if (kk == 0ull) break;
+                    sl = (sl + 1) & (TECH_SLOTS - 1);
+                }
+            }
+            if (p.mask && qset) row = p.order[r];
+        }
+        unsigned long long mine = 0ull;
+        if (__ballot(qset != 0ull) != 0ull) {  // wave-uniform: most 64-rank groups match no query at all
+            for (int q = 0; q < p.nq; ++q) {
+                bool hit = (qset >> q) & 1ull;
+                if (hit && p.mask) hit = (p.mask[(size_t)q * (size_t)p.mask_stride_w + (row >> 5)] >> (row & 31)) & 1u;
+                const unsigned long long b = __ballot(hit);
+                if (lane == q) mine = b;
+            }
+        }
+        if (lane < p.nq) p.bitmap[(size_t)(r0 >> 6) * p.nq + lane] = mine;
     }
 }
 
+constexpr int TECH_CHUNK_WORDS = 256;  // words (of 64 ranks) per selection round: one per thread
+
 __global__ __launch_bounds__(256) void tech_select_kernel(TechParams p) {
     __shared__ int s_cnt[256];
+    __shared__ int s_base;
     const int q = blockIdx.x, tid = threadIdx.x;
-    const uint64_t *bm = p.bitmap + (size_t)q * p.words;
-    const int64_t per = (p.words + 255) / 256;
-    const int64_t w0 = (int64_t)tid * per, w1 = (w0 + per < p.words) ? w0 + per : p.words;
-    int c = 0;
-    for (int64_t w = w0; w < w1; ++w) c += __popcll(bm[w]);
-    s_cnt[tid] = c;
+    if (tid == 0) s_base = 0;
     __syncthreads();
-    int before = 0;
-    for (int i = 0; i < tid; ++i) before += s_cnt[i];  // 256 entries: fine
-    int total = 0;
+    for (int64_t w0 = 0; w0 < p.words; w0 += TECH_CHUNK_WORDS) {
+        const int base = s_base;
+        if (base >= p.k) break;  // uniform: LIMIT k reached
+        const int64_t w = w0 + tid;
+        uint64_t bits = w < p.words ? p.bitmap[(size_t)w * p.nq + q] : 0ull;
+        const int c = __popcll(bits);
+        s_cnt[tid] = c;
+        __syncthreads();
+        int before = base;
+        for (int i = 0; i < tid; ++i) before += s_cnt[i];  // 256 entries: fine
+        int pos = before;
+        while (bits && pos < p.k) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const int64_t row = p.order[w * 64 + b];
+            p.out_ids[(size_t)q * p.k + pos] = p.ids ? p.ids[row] : row;
+            ++pos;
+        }
+        __syncthreads();
+        if (tid == 255) s_base = before + c;
+        __syncthreads();
+    }
     if (tid == 0) {
-        for (int i = 0; i < 256; ++i) total += s_cnt[i];
+        const int total = s_base;
         const int cnt = total < p.k ? total : p.k;
         p.out_counts[q] = cnt;
         for (int i = cnt; i < p.k; ++i) p.out_ids[(size_t)q * p.k + i] = -1;
-    }
-    if (before < p.k) {
-        int pos = before;
-        for (int64_t w = w0; w < w1 && pos < p.k; ++w) {
-            uint64_t bits = bm[w];
-            while (bits && pos < p.k) {
-                const int b = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                const int64_t row = p.order[w * 64 + b];
-                p.out_ids[(size_t)q * p.k + pos] = p.ids ? p.ids[row] : row;
-                ++pos;
-            }
-        }
     }
 }
 
@@ -274,8 +320,9 @@ extern "C" int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, 
     p.out_ids = d_out_ids;
     p.out_counts = d_out_counts;
     if (p.words == 0) p.words = 1;
-    const unsigned blocks = (unsigned)((p.words * 64 + 255) / 256);
-    hipLaunchKernelGGL(tech_match_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    int64_t blocks = (p.words * 64 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;  // persistent blocks: the LDS token table is built once per block
+    hipLaunchKernelGGL(tech_match_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(tech_select_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -61,9 +61,10 @@ class TechTokenIndex:
         ids = np.asarray(ids, dtype=np.int64)
         ts = np.asarray(call_started_at, dtype="datetime64[us]").astype(np.int64)
         order = np.lexsort((ids, -ts)).astype(np.int32)  # primary: started_at DESC, then id ASC
+        # CSR stored by rank (recency order) so the GPU scan is a coalesced stream
         row_ptr = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum([len(t) for t in row_tokens], out=row_ptr[1:])
-        toks = np.array([token_hash(t) for row in row_tokens for t in row], dtype=np.uint64)
+        np.cumsum([len(row_tokens[r]) for r in order], out=row_ptr[1:])
+        toks = np.array([token_hash(t) for r in order for t in row_tokens[r]], dtype=np.uint64)
         if toks.size == 0:
             toks = np.zeros(1, dtype=np.uint64)
         self.n = n

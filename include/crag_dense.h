@@ -129,11 +129,12 @@ int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, const int32_t *
 /* Exact-token lane for a batch of up to 64 queries (hybrid /retrieve).  Replaces: _fetch_chunks_tech /
  * _fetch_artifacts_tech (retrieve.py:183-242): rows whose token set overlaps the query's, first k in
  * the order (call_started_at DESC, id ASC).  Tokens are 64-bit hashes of the exact token strings.
- *   d_order [n] int32   row position at each rank of that static order
- *   d_row_ptr [n+1] int64, d_tokens [nnz] uint64   CSR of the rows' token hashes
+ *   d_order [n] int32   row position at each rank r of that static order
+ *   d_row_ptr [n+1] int64, d_tokens [nnz] uint64   CSR of the rows' token hashes, stored BY RANK
+ *                       (CSR row r = the row at position d_order[r]) so the scan streams coalesced
  *   d_query_tokens [nq, 32] uint64, d_query_token_counts [nq] int32 (<= 32 tokens per query)
  *   d_row_mask as in crag_index_search (bit per row POSITION; nullable)
- *   d_bitmap_scratch [nq * ceil(n/64)] uint64
+ *   d_bitmap_scratch [ceil(n/64) * nq] uint64
  *   d_out_ids [nq, k] (-1 pad), d_out_counts [nq] */
 int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint64_t *d_tokens,
                    const int64_t *d_ids, int64_t n_rows, const uint64_t *d_query_tokens,
