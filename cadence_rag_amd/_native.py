@@ -6,12 +6,14 @@ entry point raises NativeLibraryError loudly.
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 from typing import Optional
 
 _CSRC = Path(__file__).resolve().parent / "csrc"
-LIB_PATH = _CSRC / "libcrag_dense.so"
+# CRAG_DENSE_LIB: deployments that install the library elsewhere
+LIB_PATH = Path(os.environ["CRAG_DENSE_LIB"]) if os.environ.get("CRAG_DENSE_LIB") else _CSRC / "libcrag_dense.so"
 
 CRAG_MAX_K = 128
 CRAG_DIM = 1024

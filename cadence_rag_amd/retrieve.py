@@ -194,6 +194,17 @@ class DenseTable:
             rows.append(row)
         return rows
 
+    def build_tech_lane(self, row_tokens: Sequence[Sequence[str]]):
+        """GPU exact-token lane over this table's rows (row i <-> position i, so filter masks are shared):
+        the `tech_tokens text[]` column + ORDER BY call_started_at DESC, id ASC (retrieve.py:183-242)."""
+        import torch
+
+        from .fusion import TechTokenIndex
+        if len(row_tokens) != len(self):
+            raise ValueError("row_tokens must have one entry per table row")
+        return TechTokenIndex(row_tokens, np.asarray(self.columns[self.id_field], dtype=np.int64),
+                              self.call_started_at, torch.device("cuda", self.index.device))
+
     def _positions(self) -> Dict[int, int]:
         if getattr(self, "_pos_of_id", None) is None:
             self._pos_of_id = {int(v): i for i, v in enumerate(self.columns[self.id_field])}
@@ -233,3 +244,318 @@ def _fetch_artifacts_dense(table: DenseTable, query_embedding, filters: Optional
                            call_ids: Optional[Sequence[UUID]], mode: str, limit: int) -> List[Dict[str, Any]]:
     """rows: {artifact_chunk_id, artifact_id, call_id, kind, content, score}, best first."""
     return table.fetch_dense(query_embedding, filters, call_ids, mode, limit, ARTIFACT_SELECT)
+
+
+# ------------------------------------------------------------------------------------------------
+# /retrieve entry point (S9): the orchestration of /root/reference/app/retrieve.py:392-688 with the
+# SQL connection replaced by a backend object.  Lane order, RRF, ids_only ordering, evidence packing,
+# budget clipping and every `notes.retrieval` / `debug` key follow the reference; goldens captured
+# from the reference's own retrieve_evidence (tests/golden/reference_retrieve_evidence.json) pin it.
+# ------------------------------------------------------------------------------------------------
+DEFAULT_CHUNK_BM25_TOPK = 50
+DEFAULT_ARTIFACT_CHUNK_BM25_TOPK = 10
+DEFAULT_TECH_TOPK = 50
+DEFAULT_MAX_ARTIFACTS = 2
+DEFAULT_MAX_QUOTES_PER_CALL = 2
+DEFAULT_SNIPPET_CHARS = 800
+
+
+@dataclass
+class Budget:
+    """app/schemas.py:71-73."""
+    max_evidence_items: int = 8
+    max_total_chars: int = 6000
+
+    def model_dump(self) -> Dict[str, int]:
+        return {"max_evidence_items": self.max_evidence_items, "max_total_chars": self.max_total_chars}
+
+
+@dataclass
+class RetrieveRequest:
+    """app/schemas.py:85-93."""
+    query: str
+    intent: str = "auto"
+    filters: Optional[RetrieveFilters] = None
+    budget: Optional[Budget] = None
+    return_style: str = "evidence_pack_json"
+    debug: bool = False
+
+
+def _clip(text: str, max_chars: int) -> str:
+    """retrieve.py:24-29."""
+    if max_chars <= 0:
+        return ""
+    if len(text) <= max_chars:
+        return text
+    return text[: max_chars - 1].rstrip() + "…"
+
+
+def _build_debug_lane(rows: Sequence[Dict[str, Any]], id_field: str) -> List[Dict[str, Any]]:
+    """retrieve.py:32-41."""
+    return [{id_field: row[id_field], "rank": rank, "score": row.get("score")}
+            for rank, row in enumerate(rows, start=1)]
+
+
+class RetrieveBackend:
+    """What retrieve_evidence needs from storage: one method per SQL helper of the reference
+    (retrieve.py:46-389), same arguments minus the connection.  Subclass or duck-type."""
+
+    def resolve_call_ids(self, filters): return None
+    def fetch_chunks_bm25(self, query, filters, call_ids, limit): return []
+    def fetch_artifacts_bm25(self, query, filters, call_ids, limit): return []
+    def fetch_chunks_tech(self, tokens, filters, call_ids, limit): return []
+    def fetch_artifacts_tech(self, tokens, filters, call_ids, limit): return []
+    def estimate_dense_candidates(self, table_name, filters, call_ids): return 0
+    def fetch_chunks_dense(self, query_embedding, filters, call_ids, mode, limit): return []
+    def fetch_artifacts_dense(self, query_embedding, filters, call_ids, mode, limit): return []
+
+
+class GpuRetrieveBackend(RetrieveBackend):
+    """Dense lanes from the HBM-resident DenseTables, exact-token lanes from GPU TechTokenIndex objects
+    (cadence_rag_amd.fusion) when attached, BM25 lanes from injected callables (pg_search's arithmetic
+    is not in the reference repository: its rows are an input here, as they are to _rrf_merge)."""
+
+    def __init__(self, chunks: DenseTable, artifact_chunks: DenseTable, *, calls: Sequence[Dict[str, Any]] = (),
+                 bm25_chunks=None, bm25_artifacts=None, tech_chunks=None, tech_artifacts=None) -> None:
+        self.tables = {"chunks": chunks, "artifact_chunks": artifact_chunks}
+        self.calls = list(calls)
+        self._bm25 = {"chunks": bm25_chunks, "artifact_chunks": bm25_artifacts}
+        self._tech = {"chunks": tech_chunks, "artifact_chunks": tech_artifacts}
+
+    def resolve_call_ids(self, filters):
+        return _resolve_call_ids(self.calls, filters)
+
+    def fetch_chunks_bm25(self, query, filters, call_ids, limit):
+        fn = self._bm25["chunks"]
+        return list(fn(query, filters, call_ids, limit)) if fn else []
+
+    def fetch_artifacts_bm25(self, query, filters, call_ids, limit):
+        fn = self._bm25["artifact_chunks"]
+        return list(fn(query, filters, call_ids, limit)) if fn else []
+
+    def _tech_rows(self, name, select, tokens, filters, call_ids, limit):
+        lane, table = self._tech[name], self.tables[name]
+        if not tokens or lane is None or len(table) == 0:
+            return []
+        import torch
+        mask = table.filter_mask(filters, call_ids)
+        d_mask = None
+        if mask is not None:
+            d_mask = torch.from_numpy(DenseIndex.pack_mask(mask)).to(lane.device)
+        ids, counts = lane.search([list(tokens)], int(limit), row_mask=d_mask, mask_stride=0)
+        pos_of = table._positions()
+        out = []
+        for rid in ids[0, : int(counts[0])].tolist():
+            pos = pos_of[int(rid)]
+            out.append({col: table.columns[col][pos] for col in select})
+        return out
+
+    def fetch_chunks_tech(self, tokens, filters, call_ids, limit):
+        return self._tech_rows("chunks", CHUNK_SELECT, tokens, filters, call_ids, limit)
+
+    def fetch_artifacts_tech(self, tokens, filters, call_ids, limit):
+        return self._tech_rows("artifact_chunks", ARTIFACT_SELECT, tokens, filters, call_ids, limit)
+
+    def estimate_dense_candidates(self, table_name, filters, call_ids):
+        return _estimate_dense_candidates(self.tables[table_name], table_name, filters, call_ids)
+
+    def fetch_chunks_dense(self, query_embedding, filters, call_ids, mode, limit):
+        return _fetch_chunks_dense(self.tables["chunks"], query_embedding, filters, call_ids, mode, limit)
+
+    def fetch_artifacts_dense(self, query_embedding, filters, call_ids, mode, limit):
+        return _fetch_artifacts_dense(self.tables["artifact_chunks"], query_embedding, filters, call_ids, mode, limit)
+
+
+_backend: Optional[RetrieveBackend] = None
+
+
+def set_backend(backend: Optional[RetrieveBackend]) -> None:
+    """Register the process-wide backend (the counterpart of the reference's module-level `engine`)."""
+    global _backend
+    _backend = backend
+
+
+def retrieve_evidence(payload: RetrieveRequest, backend: Optional[RetrieveBackend] = None) -> Dict[str, Any]:
+    """Drop-in for retrieve_evidence (retrieve.py:392-688): same response dict, key for key."""
+    from uuid import uuid4
+
+    from . import embeddings as _emb
+    from .tech_tokens import extract_tech_tokens
+
+    be = backend if backend is not None else _backend
+    if be is None:
+        raise RuntimeError("retrieve_evidence: no backend registered (set_backend)")
+    query_id = str(uuid4())
+    query = payload.query.strip()
+    budget = payload.budget or Budget()
+    return_style = payload.return_style
+
+    if not query:
+        if return_style == "ids_only":
+            return {"query_id": query_id, "retrieved_ids": []}
+        return {"query_id": query_id, "intent": payload.intent, "budget": budget.model_dump(),
+                "artifacts": [], "quotes": [], "notes": {"error": "empty query"}}
+
+    filters = payload.filters
+    tech_tokens = extract_tech_tokens(query)
+    dense_enabled = _emb.embeddings_enabled()
+    dense_error: Optional[str] = None
+    dense_model_id: Optional[str] = None
+    query_embedding: Optional[str] = None
+    if dense_enabled:
+        try:
+            embedded = _emb.embed_texts([query])
+            dense_model_id = embedded.model
+            query_embedding = _vector_literal(embedded.vectors[0])
+        except _emb.EmbeddingClientError as exc:
+            dense_enabled = False
+            dense_error = str(exc)
+
+    dense_chunks: List[Dict[str, Any]] = []
+    dense_artifacts: List[Dict[str, Any]] = []
+    chunk_dense_mode: Optional[str] = None
+    artifact_dense_mode: Optional[str] = None
+    chunk_dense_candidates = 0
+    artifact_dense_candidates = 0
+
+    call_ids = be.resolve_call_ids(filters)
+    bm25_chunks = be.fetch_chunks_bm25(query, filters, call_ids, DEFAULT_CHUNK_BM25_TOPK)
+    bm25_artifacts = be.fetch_artifacts_bm25(query, filters, call_ids, DEFAULT_ARTIFACT_CHUNK_BM25_TOPK)
+    tech_chunks = be.fetch_chunks_tech(tech_tokens, filters, call_ids, DEFAULT_TECH_TOPK)
+    tech_artifacts = be.fetch_artifacts_tech(tech_tokens, filters, call_ids, DEFAULT_TECH_TOPK)
+    if dense_enabled and query_embedding is not None:
+        chunk_dense_candidates = be.estimate_dense_candidates("chunks", filters, call_ids)
+        artifact_dense_candidates = be.estimate_dense_candidates("artifact_chunks", filters, call_ids)
+        chunk_dense_mode = _choose_dense_mode(chunk_dense_candidates, filters, call_ids)
+        artifact_dense_mode = _choose_dense_mode(artifact_dense_candidates, filters, call_ids)
+        dense_chunks = be.fetch_chunks_dense(query_embedding, filters, call_ids, chunk_dense_mode,
+                                             DEFAULT_DENSE_CHUNK_TOPK)
+        dense_artifacts = be.fetch_artifacts_dense(query_embedding, filters, call_ids, artifact_dense_mode,
+                                                   DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK)
+
+    debug_payload = None
+    if payload.debug:
+        chunk_lanes_debug = {"bm25": _build_debug_lane(bm25_chunks, "chunk_id"),
+                             "tech_tokens": _build_debug_lane(tech_chunks, "chunk_id")}
+        artifact_lanes_debug = {"bm25": _build_debug_lane(bm25_artifacts, "artifact_chunk_id"),
+                                "tech_tokens": _build_debug_lane(tech_artifacts, "artifact_chunk_id")}
+        if dense_enabled:
+            chunk_lanes_debug["dense"] = _build_debug_lane(dense_chunks, "chunk_id")
+            artifact_lanes_debug["dense"] = _build_debug_lane(dense_artifacts, "artifact_chunk_id")
+        debug_payload = {
+            "lanes": {"chunks": chunk_lanes_debug, "artifacts": artifact_lanes_debug},
+            "limits": {
+                "bm25_chunk_topk": DEFAULT_CHUNK_BM25_TOPK,
+                "bm25_artifact_chunk_topk": DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
+                "tech_token_topk": DEFAULT_TECH_TOPK,
+                "dense_chunk_topk": DEFAULT_DENSE_CHUNK_TOPK if dense_enabled else 0,
+                "dense_artifact_chunk_topk": DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK if dense_enabled else 0,
+            },
+            "dense": {
+                "enabled": dense_enabled,
+                "model_id": dense_model_id,
+                "error": dense_error,
+                "modes": {"chunks": chunk_dense_mode, "artifact_chunks": artifact_dense_mode},
+                "candidate_rows": {"chunks": chunk_dense_candidates, "artifact_chunks": artifact_dense_candidates},
+            },
+        }
+
+    chunk_lanes: Dict[str, Sequence[Dict[str, Any]]] = {"bm25": bm25_chunks, "tech_tokens": tech_chunks}
+    artifact_lanes: Dict[str, Sequence[Dict[str, Any]]] = {"bm25": bm25_artifacts, "tech_tokens": tech_artifacts}
+    if dense_enabled:
+        chunk_lanes["dense"] = dense_chunks
+        artifact_lanes["dense"] = dense_artifacts
+    chunk_ranked = _rrf_merge(chunk_lanes, "chunk_id")
+    artifact_ranked = _rrf_merge(artifact_lanes, "artifact_chunk_id")
+
+    if return_style == "ids_only":
+        combined = [("artifact_chunk", row["artifact_chunk_id"], score) for row, _l, score in artifact_ranked]
+        combined += [("chunk", row["chunk_id"], score) for row, _l, score in chunk_ranked]
+        kind_order = {"artifact_chunk": 0, "chunk": 1}
+        combined.sort(key=lambda item: (-item[2], kind_order[item[0]], item[1]))
+        response: Dict[str, Any] = {"query_id": query_id,
+                                    "retrieved_ids": [f"{kind}:{item_id}" for kind, item_id, _ in combined]}
+        if debug_payload is not None:
+            response["debug"] = debug_payload
+        return response
+
+    max_items = budget.max_evidence_items
+    remaining_chars = budget.max_total_chars
+    artifacts_out: List[Dict[str, Any]] = []
+    quotes_out: List[Dict[str, Any]] = []
+    max_artifacts = min(DEFAULT_MAX_ARTIFACTS, max_items)
+    evidence_count = 0
+    for row, lanes, _score in artifact_ranked:
+        if evidence_count >= max_items or len(artifacts_out) >= max_artifacts:
+            break
+        if remaining_chars <= 0:
+            break
+        snippet = _clip(row["content"], min(DEFAULT_SNIPPET_CHARS, remaining_chars))
+        remaining_chars -= len(snippet)
+        artifacts_out.append({
+            "evidence_id": f"A-{row['artifact_chunk_id']}",
+            "call_id": str(row["call_id"]),
+            "artifact_id": row["artifact_id"],
+            "artifact_chunk_id": row["artifact_chunk_id"],
+            "kind": row["kind"],
+            "snippet": snippet,
+            "why_relevant": " + ".join(sorted(lanes)),
+        })
+        evidence_count += 1
+
+    quotes_per_call: Dict[str, int] = {}
+    for row, lanes, _score in chunk_ranked:
+        if evidence_count >= max_items:
+            break
+        if remaining_chars <= 0:
+            break
+        call_id = str(row["call_id"])
+        if quotes_per_call.get(call_id, 0) >= DEFAULT_MAX_QUOTES_PER_CALL:
+            continue
+        snippet = _clip(row["text"], min(DEFAULT_SNIPPET_CHARS, remaining_chars))
+        remaining_chars -= len(snippet)
+        quotes_out.append({
+            "evidence_id": f"Q-{row['chunk_id']}",
+            "call_id": call_id,
+            "chunk_id": row["chunk_id"],
+            "speaker": row["speaker"],
+            "start_ts_ms": row["start_ts_ms"],
+            "end_ts_ms": row["end_ts_ms"],
+            "snippet": snippet,
+            "why_relevant": " + ".join(sorted(lanes)),
+        })
+        quotes_per_call[call_id] = quotes_per_call.get(call_id, 0) + 1
+        evidence_count += 1
+
+    planner = ("lexical_only" if not dense_enabled
+               else ("ann" if (chunk_dense_mode == "ann" or artifact_dense_mode == "ann") else "exact"))
+    response = {
+        "query_id": query_id,
+        "intent": payload.intent,
+        "budget": budget.model_dump(),
+        "artifacts": artifacts_out,
+        "quotes": quotes_out,
+        "notes": {
+            "retrieval": {
+                "planner": planner,
+                "dense_topk": max(DEFAULT_DENSE_CHUNK_TOPK, DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK) if dense_enabled else 0,
+                "lex_topk": DEFAULT_CHUNK_BM25_TOPK,
+                "artifact_chunk_lex_topk": DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
+                "reranked_from": None,
+                "bm25_chunk_topk": DEFAULT_CHUNK_BM25_TOPK,
+                "bm25_artifact_chunk_topk": DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
+                "tech_token_topk": DEFAULT_TECH_TOPK,
+                "tech_tokens": tech_tokens,
+                "lanes": {"bm25": True, "tech_tokens": True, "dense": dense_enabled},
+                "dense_model_id": dense_model_id,
+                "dense_error": dense_error,
+                "dense_modes": {"chunks": chunk_dense_mode, "artifact_chunks": artifact_dense_mode},
+                "dense_candidate_rows": {"chunks": chunk_dense_candidates,
+                                         "artifact_chunks": artifact_dense_candidates},
+                "hnsw_ef_search": settings.embeddings_hnsw_ef_search if dense_enabled else None,
+            }
+        },
+    }
+    if debug_payload is not None:
+        response["debug"] = debug_payload
+    return response

@@ -239,6 +239,9 @@ def main() -> None:
     out["compute_metrics"] = {"gold": gold, "results": results, "ks": [1, 2, 10],
                               "metrics": compute_metrics(gold, results, [1, 2, 10])}
 
+    # --- S9 retrieve_evidence (retrieve.py:392-688): orchestration, RRF, evidence packing ------
+    _retrieve_evidence_goldens(retrieve, embeddings)
+
     (HERE / "reference_host_logic.json").write_text(json.dumps(out, indent=1, sort_keys=True, default=str) + "\n")
     print("wrote", HERE / "reference_host_logic.json")
 
@@ -276,6 +279,113 @@ def main() -> None:
                         mask=mask, masked_ids=ids3.astype(np.int32), masked_scores=scores3,
                         masked_counts=counts3)
     print("wrote dense fixtures")
+
+
+def _retrieve_evidence_goldens(retrieve, embeddings) -> None:
+    """Run the reference's retrieve_evidence with its SQL helpers replaced by canned lane rows and
+    record (inputs, response) pairs.  Only values are stored."""
+    from contextlib import contextmanager
+
+    from app.schemas import Budget, RetrieveFilters, RetrieveRequest
+
+    calls = ["7f0c1d3e-0000-4000-8000-00000000000%d" % i for i in range(5)]
+
+    def chunk(cid, call, text, speaker="A", score=None):
+        row = {"chunk_id": cid, "call_id": calls[call], "speaker": speaker, "start_ts_ms": cid * 1000,
+               "end_ts_ms": cid * 1000 + 900, "text": text}
+        if score is not None:
+            row["score"] = score
+        return row
+
+    def art(aid, call, content, kind="summary", score=None):
+        row = {"artifact_chunk_id": aid, "artifact_id": 100 + aid, "call_id": calls[call], "kind": kind,
+               "content": content}
+        if score is not None:
+            row["score"] = score
+        return row
+
+    long_text = ("The rollout of build 2024.11.3 failed on node gpu-17 with ECC errors. " * 20).strip()
+    lanes = {
+        "bm25_chunks": [chunk(11, 0, long_text, score=9.5), chunk(12, 0, "second chunk of call zero", score=7.25),
+                        chunk(13, 0, "third chunk of call zero", score=7.0), chunk(21, 1, "call one talks about ERR-4521", score=6.5),
+                        chunk(31, 2, "short", score=1.0)],
+        "bm25_artifacts": [art(5, 0, long_text, score=4.0), art(6, 1, "decision: roll back", kind="decisions", score=3.0),
+                           art(7, 2, "action: file ticket OPS-99", kind="action_items", score=2.0)],
+        "tech_chunks": [chunk(21, 1, "call one talks about ERR-4521"), chunk(41, 3, "ERR-4521 seen again")],
+        "tech_artifacts": [art(7, 2, "action: file ticket OPS-99", kind="action_items")],
+        "dense_chunks": [chunk(12, 0, "second chunk of call zero", score=0.91), chunk(41, 3, "ERR-4521 seen again", score=0.9),
+                         chunk(51, 4, "unrelated but close", score=0.5), chunk(11, 0, long_text, score=0.4)],
+        "dense_artifacts": [art(6, 1, "decision: roll back", kind="decisions", score=0.8), art(8, 3, "summary of call three", score=0.7)],
+    }
+    scenarios = [
+        {"name": "evidence_pack_dense", "payload": {"query": "  why did ERR-4521 happen on gpu-17?  "},
+         "dense": "ok", "candidates": {"chunks": 120000, "artifact_chunks": 900}},
+        {"name": "ids_only_debug", "payload": {"query": "ERR-4521 rollback", "return_style": "ids_only", "debug": True},
+         "dense": "ok", "candidates": {"chunks": 120000, "artifact_chunks": 900}},
+        {"name": "evidence_pack_debug_scoped_exact", "payload": {"query": "ERR-4521 rollback", "debug": True,
+                                                                  "filters": {"call_ids": [calls[0], calls[1]]}},
+         "dense": "ok", "candidates": {"chunks": 400, "artifact_chunks": 0}, "call_ids": [calls[0], calls[1]]},
+        {"name": "embedding_error_falls_back", "payload": {"query": "ERR-4521 rollback", "intent": "troubleshooting"},
+         "dense": "error", "candidates": {"chunks": 5, "artifact_chunks": 5}},
+        {"name": "dense_disabled", "payload": {"query": "ERR-4521 rollback"}, "dense": "off",
+         "candidates": {"chunks": 5, "artifact_chunks": 5}},
+        {"name": "small_budget", "payload": {"query": "ERR-4521 rollback", "budget": {"max_evidence_items": 3, "max_total_chars": 500}},
+         "dense": "ok", "candidates": {"chunks": 10, "artifact_chunks": 10}},
+        {"name": "one_item_budget", "payload": {"query": "ERR-4521 rollback", "budget": {"max_evidence_items": 1, "max_total_chars": 50}},
+         "dense": "ok", "candidates": {"chunks": 10, "artifact_chunks": 10}},
+        {"name": "empty_query_pack", "payload": {"query": "   "}, "dense": "ok", "candidates": {"chunks": 0, "artifact_chunks": 0}},
+        {"name": "empty_query_ids", "payload": {"query": "", "return_style": "ids_only"}, "dense": "ok",
+         "candidates": {"chunks": 0, "artifact_chunks": 0}},
+        {"name": "no_tech_tokens_query", "payload": {"query": "what was decided about the budget", "return_style": "ids_only"},
+         "dense": "ok", "candidates": {"chunks": 120000, "artifact_chunks": 120000}},
+    ]
+
+    class _Engine:
+        @contextmanager
+        def connect(self):
+            yield object()
+
+    saved = {name: getattr(retrieve, name) for name in (
+        "engine", "_resolve_call_ids", "_fetch_chunks_bm25", "_fetch_artifacts_bm25", "_fetch_chunks_tech",
+        "_fetch_artifacts_tech", "_estimate_dense_candidates", "_fetch_chunks_dense", "_fetch_artifacts_dense",
+        "embeddings_enabled", "embed_texts")}
+    results = []
+    try:
+        retrieve.engine = _Engine()
+        for sc in scenarios:
+            from uuid import UUID
+            cids = [UUID(c) for c in sc["call_ids"]] if sc.get("call_ids") else None
+            retrieve._resolve_call_ids = lambda conn, filters, _c=cids: _c
+            retrieve._fetch_chunks_bm25 = lambda conn, q, f, c, k: [dict(r) for r in lanes["bm25_chunks"]][:k]
+            retrieve._fetch_artifacts_bm25 = lambda conn, q, f, c, k: [dict(r) for r in lanes["bm25_artifacts"]][:k]
+            retrieve._fetch_chunks_tech = lambda conn, t, f, c, k: ([dict(r) for r in lanes["tech_chunks"]][:k] if t else [])
+            retrieve._fetch_artifacts_tech = lambda conn, t, f, c, k: ([dict(r) for r in lanes["tech_artifacts"]][:k] if t else [])
+            retrieve._estimate_dense_candidates = lambda conn, table, f, c, _sc=sc: _sc["candidates"][table]
+            retrieve._fetch_chunks_dense = lambda conn, e, f, c, m, k: [dict(r) for r in lanes["dense_chunks"]][:k]
+            retrieve._fetch_artifacts_dense = lambda conn, e, f, c, m, k: [dict(r) for r in lanes["dense_artifacts"]][:k]
+            retrieve.embeddings_enabled = lambda _sc=sc: _sc["dense"] != "off"
+
+            def fake_embed(texts, _sc=sc):
+                if _sc["dense"] == "error":
+                    raise embeddings.EmbeddingClientError("embedding request failed: connection refused")
+                return embeddings.EmbeddingResult(vectors=[[0.25] * 1024 for _ in texts], model="Qwen/Qwen3-Embedding-4B")
+
+            retrieve.embed_texts = fake_embed
+            pl = dict(sc["payload"])
+            if "filters" in pl:
+                pl["filters"] = RetrieveFilters(**pl["filters"])
+            if "budget" in pl:
+                pl["budget"] = Budget(**pl["budget"])
+            resp = retrieve.retrieve_evidence(RetrieveRequest(**pl))
+            resp.pop("query_id")
+            results.append({"name": sc["name"], "payload": sc["payload"], "dense": sc["dense"],
+                            "candidates": sc["candidates"], "call_ids": sc.get("call_ids"), "response": resp})
+    finally:
+        for name, val in saved.items():
+            setattr(retrieve, name, val)
+    (HERE / "reference_retrieve_evidence.json").write_text(
+        json.dumps({"lanes": lanes, "scenarios": results}, indent=1, default=str) + "\n")
+    print("wrote", HERE / "reference_retrieve_evidence.json")
 
 
 if __name__ == "__main__":

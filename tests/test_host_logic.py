@@ -360,3 +360,76 @@ def test_resolve_call_ids_semantics():
     assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="X", external_source="crm")) == [a]
     assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="X", call_ids=[b, c])) == [b]
     assert rt._resolve_call_ids(calls, rt.RetrieveFilters(external_id="nope")) == []
+
+
+# ---- S9: retrieve_evidence orchestration vs the reference's own responses ---------------------
+def _load_retrieve_goldens():
+    import json
+    from pathlib import Path
+    return json.loads((Path(__file__).parent / "golden" / "reference_retrieve_evidence.json").read_text())
+
+
+class _ReplayBackend:
+    """Serves the canned lane rows the goldens were captured with (the reference's SQL helpers were
+    replaced by the same rows in tests/golden/make_goldens.py)."""
+
+    def __init__(self, lanes, scenario):
+        from uuid import UUID
+        self.lanes, self.sc = lanes, scenario
+        self.call_ids = [UUID(c) for c in scenario["call_ids"]] if scenario.get("call_ids") else None
+        self.seen = []
+
+    def resolve_call_ids(self, filters): return self.call_ids
+    def fetch_chunks_bm25(self, q, f, c, k): return [dict(r) for r in self.lanes["bm25_chunks"]][:k]
+    def fetch_artifacts_bm25(self, q, f, c, k): return [dict(r) for r in self.lanes["bm25_artifacts"]][:k]
+    def fetch_chunks_tech(self, t, f, c, k): return [dict(r) for r in self.lanes["tech_chunks"]][:k] if t else []
+    def fetch_artifacts_tech(self, t, f, c, k): return [dict(r) for r in self.lanes["tech_artifacts"]][:k] if t else []
+    def estimate_dense_candidates(self, table, f, c): return self.sc["candidates"][table]
+
+    def fetch_chunks_dense(self, e, f, c, mode, k):
+        self.seen.append(("chunks", mode, k, e[:12]))
+        return [dict(r) for r in self.lanes["dense_chunks"]][:k]
+
+    def fetch_artifacts_dense(self, e, f, c, mode, k):
+        self.seen.append(("artifact_chunks", mode, k, e[:12]))
+        return [dict(r) for r in self.lanes["dense_artifacts"]][:k]
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_retrieve_evidence_matches_reference_responses(monkeypatch, idx):
+    from uuid import UUID
+
+    from cadence_rag_amd import embeddings, retrieve
+    gold = _load_retrieve_goldens()
+    sc = gold["scenarios"][idx]
+    monkeypatch.setattr(embeddings, "embeddings_enabled", lambda: sc["dense"] != "off")
+
+    def fake_embed(texts):
+        if sc["dense"] == "error":
+            raise embeddings.EmbeddingClientError("embedding request failed: connection refused")
+        return embeddings.EmbeddingResult(vectors=[[0.25] * 1024 for _ in texts], model="Qwen/Qwen3-Embedding-4B")
+
+    monkeypatch.setattr(embeddings, "embed_texts", fake_embed)
+    pl = dict(sc["payload"])
+    if "filters" in pl:
+        f = dict(pl["filters"])
+        if f.get("call_ids"):
+            f["call_ids"] = [UUID(c) for c in f["call_ids"]]
+        pl["filters"] = retrieve.RetrieveFilters(**f)
+    if "budget" in pl:
+        pl["budget"] = retrieve.Budget(**pl["budget"])
+    be = _ReplayBackend(gold["lanes"], sc)
+    resp = retrieve.retrieve_evidence(retrieve.RetrieveRequest(**pl), be)
+    assert UUID(resp.pop("query_id"))
+    assert resp == sc["response"], sc["name"]
+    if sc["dense"] == "ok" and sc["payload"]["query"].strip():
+        # the dense helpers got the .10g vector literal and the planner's mode, k = 50 / 10
+        assert [s[0] for s in be.seen] == ["chunks", "artifact_chunks"]
+        assert be.seen[0][2] == 50 and be.seen[1][2] == 10 and be.seen[0][3].startswith("[0.25,0.25")
+
+
+def test_retrieve_evidence_needs_a_backend():
+    from cadence_rag_amd import retrieve
+    retrieve.set_backend(None)
+    with pytest.raises(RuntimeError, match="no backend"):
+        retrieve.retrieve_evidence(retrieve.RetrieveRequest(query="x"))

@@ -405,3 +405,100 @@ def test_gpu_tech_token_lane_matches_sql_semantics(gpu):
             assert got_ids[qi, :len(want)].tolist() == want
             assert np.all(got_ids[qi, len(want):] == -1)
     assert qtoks[2] == [] and got_ct[2] == 0
+
+
+def test_retrieve_evidence_over_gpu_backend_matches_cpu_composition(gpu, monkeypatch):
+    """The /retrieve entry point over GpuRetrieveBackend (dense + exact-token lanes on the GPU, BM25 rows
+    injected) against the same orchestration fed by the CPU oracle and a Python token filter."""
+    from datetime import datetime, timedelta
+    from uuid import UUID
+
+    from cadence_rag_amd import embeddings
+    from cadence_rag_amd.tech_tokens import extract_tech_tokens
+    rng = np.random.default_rng(77)
+    vocab = ["ERR-4521", "gpu-17", "v2.4.1", "OPS-99", "10.0.0.7", "ECONNRESET"]
+    t0 = datetime(2026, 3, 1)
+    calls = [{"call_id": UUID(int=i + 1), "external_id": f"ext-{i}", "external_source": "zoom"} for i in range(6)]
+
+    def make(name, id_field, n, select_extra):
+        vecs = unit_rows(rng, n)
+        call = [calls[i % 6]["call_id"] for i in range(n)]
+        cols = {id_field: [1000 + i for i in range(n)], "call_id": call}
+        cols.update(select_extra(n))
+        started = [t0 + timedelta(days=(i % 6)) for i in range(n)]
+        toks = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(n)]
+        table = rt.DenseTable(name, id_field, dim=1024, capacity=n)
+        table.add(vecs, cols, call_started_at=started, call_tags={c["call_id"]: ["t%d" % (i % 2)] for i, c in enumerate(calls)})
+        return table, vecs, toks, started
+
+    chunks, cvec, ctok, cstart = make("chunks", "chunk_id", 700, lambda n: {
+        "speaker": ["S%d" % (i % 3) for i in range(n)], "start_ts_ms": [i * 10 for i in range(n)],
+        "end_ts_ms": [i * 10 + 9 for i in range(n)], "text": ["chunk text %d " % i * 3 for i in range(n)]})
+    arts, avec, atok, astart = make("artifact_chunks", "artifact_chunk_id", 90, lambda n: {
+        "artifact_id": [i // 3 for i in range(n)], "kind": ["summary"] * n, "content": ["artifact %d" % i for i in range(n)]})
+    bm25_c = [{k: chunks.columns[k][p] for k in rt.CHUNK_SELECT} | {"score": 5.0 - j} for j, p in enumerate([3, 77, 500])]
+    qvec = (cvec[77] + 0.5 * avec[5]).astype(np.float32)
+    monkeypatch.setattr(embeddings, "embeddings_enabled", lambda: True)
+    monkeypatch.setattr(embeddings, "embed_texts",
+                        lambda texts: embeddings.EmbeddingResult(vectors=[qvec.tolist() for _ in texts], model="m"))
+
+    class CpuBackend(rt.RetrieveBackend):
+        def resolve_call_ids(self, filters): return rt._resolve_call_ids(calls, filters)
+        def fetch_chunks_bm25(self, q, f, c, k): return [dict(r) for r in bm25_c][:k]
+
+        def _mask(self, table, f, c):
+            m = table.filter_mask(f, c)
+            return np.ones(len(table), bool) if m is None else m
+
+        def _tech(self, table, toks_by_row, started, select, t, f, c, k):
+            if not t:
+                return []
+            m = self._mask(table, f, c)
+            ids = table.columns[table.id_field]
+            hits = [i for i in range(len(table)) if m[i] and set(t) & set(toks_by_row[i])]
+            hits.sort(key=lambda i: (-np.datetime64(started[i], "us").astype(np.int64), ids[i]))
+            return [{col: table.columns[col][i] for col in select} for i in hits[:k]]
+
+        def fetch_chunks_tech(self, t, f, c, k): return self._tech(chunks, ctok, cstart, rt.CHUNK_SELECT, t, f, c, k)
+        def fetch_artifacts_tech(self, t, f, c, k): return self._tech(arts, atok, astart, rt.ARTIFACT_SELECT, t, f, c, k)
+
+        def estimate_dense_candidates(self, name, f, c):
+            return int(self._mask(chunks if name == "chunks" else arts, f, c).sum())
+
+        def _dense(self, table, vecs, select, e, f, c, k):
+            m = self._mask(table, f, c)
+            ids, sc, ct = oracle.exact_topk(rt._parse_vector(e)[None], vecs, k,
+                                            mask=np.packbits(m, bitorder="little"), mode=oracle.F64)
+            return [{col: table.columns[col][int(p)] for col in select} | {"score": float(s)}
+                    for p, s in zip(ids[0, :ct[0]], sc[0, :ct[0]])]
+
+        def fetch_chunks_dense(self, e, f, c, mode, k): return self._dense(chunks, cvec, rt.CHUNK_SELECT, e, f, c, k)
+        def fetch_artifacts_dense(self, e, f, c, mode, k): return self._dense(arts, avec, rt.ARTIFACT_SELECT, e, f, c, k)
+
+    try:
+        gpu_be = rt.GpuRetrieveBackend(chunks, arts, calls=calls, bm25_chunks=lambda q, f, c, k: bm25_c[:k],
+                                       tech_chunks=chunks.build_tech_lane(ctok), tech_artifacts=arts.build_tech_lane(atok))
+        cases = [
+            rt.RetrieveRequest(query="why ERR-4521 on gpu-17 after v2.4.1?", debug=True),
+            rt.RetrieveRequest(query="why ERR-4521 on gpu-17 after v2.4.1?", return_style="ids_only"),
+            rt.RetrieveRequest(query="OPS-99 status", debug=True, return_style="ids_only",
+                               filters=rt.RetrieveFilters(call_ids=[calls[1]["call_id"], calls[4]["call_id"]])),
+            rt.RetrieveRequest(query="ECONNRESET 10.0.0.7", debug=True,
+                               filters=rt.RetrieveFilters(date_from=t0 + timedelta(days=2), call_tags=["t1"]),
+                               budget=rt.Budget(max_evidence_items=5, max_total_chars=300)),
+            rt.RetrieveRequest(query="no technical tokens at all", debug=True, return_style="ids_only"),
+        ]
+        for req in cases:
+            got = rt.retrieve_evidence(req, gpu_be)
+            want = rt.retrieve_evidence(req, CpuBackend())
+            got.pop("query_id"); want.pop("query_id")
+            # dense scores agree to fp32 rounding, everything else exactly
+            for side in (got, want):
+                for lanes in side.get("debug", {}).get("lanes", {}).values():
+                    for row in lanes.get("dense", []):
+                        row["score"] = round(row["score"], 5)
+            assert got == want, req
+            if req.return_style != "ids_only":
+                assert got["notes"]["retrieval"]["lanes"] == {"bm25": True, "tech_tokens": True, "dense": True}
+    finally:
+        chunks.close(); arts.close()
