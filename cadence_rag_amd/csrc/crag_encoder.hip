@@ -209,14 +209,17 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const u16 *qkv, u16 *v
     }
     __syncthreads();
     {
-        // each thread writes 16 slots (32 B) of one d row: 128 d rows x 2 halves = 256 threads
+        // each thread writes 16 slots (32 B) of one d row: 128 d rows x 2 halves = 256 threads.
+        // Inside a 32-slot block the slots are stored in PV-fragment order (see attention_kernel): stored
+        // index 16 s2 + 8 h + 4 g + r holds slot 16 s2 + 8 g + 4 h + r, so that the 8 keys one lane feeds
+        // to one PV MFMA are 16 contiguous bytes.
         const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
         u16 *dst = vt + ((int64_t)kvh * CRAG_HEAD_DIM + d) * t_pad + p0 + half * 16;
         Pack8 o0, o1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            o0.v[e] = tile[half * 16 + e][d];
-            o1.v[e] = tile[half * 16 + 8 + e][d];
+            o0.v[e] = tile[half * 16 + 8 * (e >> 2) + (e & 3)][d];      // h = 0
+            o1.v[e] = tile[half * 16 + 8 * (e >> 2) + 4 + (e & 3)][d];  // h = 1
         }
         reinterpret_cast<Pack8 *>(dst)[0] = o0;
         reinterpret_cast<Pack8 *>(dst)[1] = o1;
@@ -241,12 +244,26 @@ struct AttnParams {
 
 __device__ __forceinline__ bf16x8 ld_frag(const u16 *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 
-__global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int group = p.hq / p.hkv;  // query heads per kv head = waves per workgroup
+// The 4 (hq/hkv) waves of a workgroup are the query heads of one GQA group: they need the SAME K and V
+// tiles.  Loading fragments straight from global memory uses 32 B of every 128-B line per instruction
+// and repeats the traffic per wave, which makes the kernel L1-bound; instead the workgroup stages each
+// 32-key tile once, fully coalesced, in LDS (double-buffered, one barrier per tile) and the waves read
+// their MFMA fragments from there (rows padded to 272 / 80 bytes: conflict-free ds_read_b128).
+constexpr int ATT_KROW = 136;   // u16 per staged K row (128 + 8 pad)
+constexpr int ATT_VROW = 40;    // u16 per staged V^T row (32 + 8 pad)
+constexpr int ATT_MAX_WAVES = 8;
+
+template <int GROUP>
+__global__ __launch_bounds__(64 * GROUP) __attribute__((amdgpu_waves_per_eu(2, 8)))
+void attention_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) u16 s_k[2][32 * ATT_KROW];
+    __shared__ __attribute__((aligned(16))) u16 s_v[2][CRAG_HEAD_DIM * ATT_VROW];
+    constexpr int nthr = 64 * GROUP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const int kvh = blockIdx.y;
-    const int head = kvh * group + wave;
+    const int head = kvh * GROUP + wave;  // GROUP = query heads per kv head = waves per workgroup
     const int seq = p.blk_seq[blockIdx.x];
     const int q0 = p.blk_q0[blockIdx.x];
     const int s_begin = p.cu[seq];
@@ -266,18 +283,62 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
     f32x16 oacc[4] = {zero, zero, zero, zero};
     float m = -INFINITY, l = 0.f;
     const int n_kt = q0 / 32 + 1;
-    const u16 *kbase = p.qkv + (int64_t)s_begin * row_stride + (int64_t)(p.hq + kvh) * CRAG_HEAD_DIM + 8 * h;
-    const u16 *vbase = p.vt + (int64_t)kvh * CRAG_HEAD_DIM * p.t_pad + pad_base;
+    const u16 *kglob = p.qkv + (int64_t)s_begin * row_stride + (int64_t)(p.hq + kvh) * CRAG_HEAD_DIM;
+    const u16 *vglob = p.vt + (int64_t)kvh * CRAG_HEAD_DIM * p.t_pad + pad_base;
+
+    // cooperative staging: the K tile is 32 rows x 16 chunks of 16 B, the V^T tile 128 rows x 4 chunks; with
+    // `nthr` threads every thread moves 512 / nthr chunks of each (nthr = 64 * group, group in {1, 2, 4, 8})
+    constexpr int per = 512 / nthr;
+    struct Stage {
+        bf16x8 k[per], v[per];
+    };
+    auto fetch = [&](int kt, Stage &st) {
+        const int k0 = kt * 32;
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int ch = tid + i * nthr;
+            st.k[i] = ld_frag(kglob + (int64_t)(k0 + (ch >> 4)) * row_stride + 8 * (ch & 15));
+            st.v[i] = ld_frag(vglob + (int64_t)(ch >> 2) * p.t_pad + k0 + 8 * (ch & 3));
+        }
+    };
+    auto stash = [&](int buf, const Stage &st) {
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int ch = tid + i * nthr;
+            *reinterpret_cast<bf16x8 *>(&s_k[buf][(ch >> 4) * ATT_KROW + 8 * (ch & 15)]) = st.k[i];
+            *reinterpret_cast<bf16x8 *>(&s_v[buf][(ch >> 2) * ATT_VROW + 8 * (ch & 3)]) = st.v[i];
+        }
+    };
+    Stage st;
+    fetch(0, st);
+    stash(0, st);
+    __syncthreads();
+    // empty the compiler's vmcnt scoreboard: otherwise the loop keeps conservative waits on the Q fragment
+    // loads above in every iteration and drains the prefetch issued at the top of each tile
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
     for (int kt = 0; kt < n_kt; ++kt) {
-        const int k0 = kt * 32;
-        f32x16 sacc = zero;
+        const int k0 = kt * 32, buf = kt & 1;
+        if (kt + 1 < n_kt) fetch(kt + 1, st);  // in flight during this tile's MFMAs and softmax
+        // all 8 K fragments first, then the MFMA chain: LDS latency is paid once, not per MFMA
+        bf16x8 fr[8];
         {
-            const u16 *kp = kbase + (int64_t)(k0 + c) * row_stride;  // A[row = key c][k = 8h + j]
+            const u16 *kp = &s_k[buf][c * ATT_KROW + 8 * h];  // A[row = key c][k = 8h + j]
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_frag(kp + 16 * s), qf[s], sacc, 0, 0, 0);
+            for (int s = 0; s < 8; ++s) fr[s] = *reinterpret_cast<const bf16x8 *>(kp + 16 * s);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 sacc = zero;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s], qf[s], sacc, 0, 0, 0);
+        // V^T fragments into the same registers while the softmax runs:
+        // A operand V^T[d = 32 dt + c][8 keys of (s2, h)], contiguous in the staged (PV-fragment) order
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                fr[2 * dt + s2] = *reinterpret_cast<const bf16x8 *>(&s_v[buf][(32 * dt + c) * ATT_VROW + 8 * h + 16 * s2]);
+        __builtin_amdgcn_sched_barrier(0);
         // lane: query row q0 + c; register i: key k0 + (i&3) + 8*(i>>2) + 4h
         float sv[16];
         float mloc = -INFINITY;
@@ -301,30 +362,27 @@ __global__ __launch_bounds__(512) void attention_kernel(AttnParams p) {
         }
         lsum += __shfl_xor(lsum, 32);
         l = l * alpha + lsum;
+        if (__any(mnew != m)) {  // wave-uniform: once the running maxima have settled no rescale is needed
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+        }
         m = mnew;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
         // P^T fragments (B operand of k-step s2): element j = register 8*s2 + j
         bf16x8 pf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pf[s2][jj] = (short)f2bf(sv[8 * s2 + jj]);
-        // A operand: V^T[d = 32 dt + c][key], element j <-> key k0 + 16 s2 + 8 (j>>2) + 4h + (j&3)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const u16 *vp = vbase + (int64_t)(32 * dt + c) * p.t_pad + k0 + 4 * h;
+        for (int s2 = 0; s2 < 2; ++s2)  // 4 independent accumulator chains
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const uint2 lo = *reinterpret_cast<const uint2 *>(vp + 16 * s2);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(vp + 16 * s2 + 8);
-                const uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[s2],
-                                                                   oacc[dt], 0, 0, 0);
-            }
-        }
+            for (int dt = 0; dt < 4; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[2 * dt + s2], pf[s2], oacc[dt], 0, 0, 0);
+        if (kt + 1 < n_kt) stash(buf ^ 1, st);  // that buffer was last read in tile kt-1, before the previous barrier
+        __syncthreads();
     }
     // O[q0 + c][32 dt + (i&3) + 8 (i>>2) + 4h] = oacc[dt][i] / l : 4 consecutive d per register quad
     if (q0 + c < len) {
@@ -457,7 +515,8 @@ int crag_enc_attention(const uint16_t *qkv, const uint16_t *vt, uint16_t *out, c
                        const int32_t *cu_pad, const int32_t *blk_seq, const int32_t *blk_q0, int n_blocks,
                        int64_t t_pad, int hq, int hkv, float scale, void *stream) {
     if (!qkv || !vt || !out || !cu_seqlens || !cu_pad || !blk_seq || !blk_q0) return efail("attention: NULL pointer");
-    if (hkv <= 0 || hq % hkv != 0 || hq / hkv > 8) return efail("attention: hq/hkv must be an integer <= 8");
+    if (hkv <= 0 || hq % hkv != 0 || (hq / hkv != 1 && hq / hkv != 2 && hq / hkv != 4 && hq / hkv != 8))
+        return efail("attention: hq/hkv must be 1, 2, 4 or 8");
     if (n_blocks <= 0) return 0;
     AttnParams p;
     p.qkv = qkv;
@@ -471,8 +530,13 @@ int crag_enc_attention(const uint16_t *qkv, const uint16_t *vt, uint16_t *out, c
     p.hq = hq;
     p.hkv = hkv;
     p.scale_log2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)n_blocks, (unsigned)hkv), dim3(64 * (hq / hkv)), 0,
-                       (hipStream_t)stream, p);
+    const dim3 grid((unsigned)n_blocks, (unsigned)hkv);
+    switch (hq / hkv) {
+        case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, (hipStream_t)stream, p); break;
+        case 4: hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    }
     return hip_ok("attention");
 }
 

@@ -28,9 +28,6 @@
 
 #include "crag_kernels.h"
 
-#ifndef CRAG_EXP
-#define CRAG_EXP 0
-#endif
 namespace crag {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1064,11 +1061,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 constexpr int grp = m >> 4, r16 = m & 15, qb = r16 >> 3, s = 2 * grp + ((r16 >> 2) & 1), cc = r16 & 3,
                               slot = s & 7;
                 acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
-#if CRAG_EXP == 2 || CRAG_EXP == 7
-                if constexpr (false) {
-#else
                 if constexpr (r16 == 15) {  // both ring slots of the group consumed: refill for steps +8
-#endif
 #pragma unroll
                     for (int ds = 0; ds < 2; ++ds) {
                         constexpr int base = 2 * grp;
@@ -1082,14 +1075,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], acc[0]);
                 if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
             }
-#if CRAG_EXP == 3 || CRAG_EXP == 5 || CRAG_EXP == 7
-            if constexpr (m == 0 || m == 60) { __syncthreads(); }
-            if constexpr (false) {
-#elif CRAG_EXP == 6
-            if constexpr (false) {
-#else
             if constexpr ((m & 1) == 0) {
-#endif
                 constexpr int o = m >> 1;
                 if constexpr (o < PIPE_OPS) pipe2_bg<o, 0, NQB, KS>(p, c, c2, L, rbuf, st);
                 else if constexpr (NQB == 2 && o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, NQB - 1, NQB, KS>(p, c, c2, L, rbuf, st);
@@ -1116,13 +1102,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 // after which the accumulators of THIS tile may overwrite it
                 __syncthreads();
             }
-#if CRAG_EXP == 1
-            if constexpr (m == 1) {
-#elif CRAG_EXP >= 3
-            if constexpr (false) {
-#else
             if constexpr (m == LOADS) {  // epilogue operands of this tile, consumed from slot TINFO on
-#endif
 #pragma unroll
                 for (int q2 = 0; q2 < NQB; ++q2)
 #pragma unroll
@@ -1142,11 +1122,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
             }
             // epilogue operands of THIS tile -> LDS, one list per odd slot TINFO.. (the ops that still read the
             // previous tile's entries finished long before)
-#if CRAG_EXP == 3 || CRAG_EXP >= 5
-            if constexpr (false) {
-#else
             if constexpr ((m & 1) == 1 && m >= TINFO) {
-#endif
                 constexpr int idx = (m - TINFO) >> 1, q2 = idx >> 1, e = idx & 1;
                 const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_row > 0.f);
                 const float scale = (row_ok && ((mword[q2][e] >> j) & 1u)) ? inv_row * L.qinv[w][q2][e][c.h] : 0.f;
@@ -1157,9 +1133,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
             __builtin_amdgcn_sched_barrier(0);
         });
         const int sbuf = NQB == 2 ? 0 : wbuf;
-#if CRAG_EXP == 5
-        if (acc[0][0] == 12345.678f && acc[NQB - 1][5] == 3.f)
-#endif
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll

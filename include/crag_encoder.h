@@ -42,7 +42,9 @@ int crag_enc_qk_norm_rope(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_
 
 /* V part of qkv -> Vt[hkv][128][t_pad] (keys on the fast axis, each sequence starting at a
  * 32-aligned padded offset, pads zero).  tok_of_pad[t_pad] int32: packed token of a padded slot
- * or -1. */
+ * or -1.  Inside every 32-slot block the slots are stored in the order the attention kernel's PV
+ * fragments consume them: stored index 16*s2 + 8*h + 4*g + r holds slot 16*s2 + 8*g + 4*h + r
+ * (s2, h, g in {0,1}, r in 0..3), i.e. one lane's 8 keys of one MFMA are 16 contiguous bytes. */
 int crag_enc_v_transpose(const uint16_t *qkv, uint16_t *vt, const int32_t *tok_of_pad, int64_t t_pad,
                          int hq, int hkv, void *stream);
 

@@ -117,7 +117,11 @@ def test_v_transpose_and_attention(gpu, lens, hq, hkv):
     tok = batch.tok_of_pad.long()
     want_vt = torch.zeros(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
     want_vt[:, :, tok >= 0] = v[tok[tok >= 0]].permute(1, 2, 0)
-    assert torch.equal(vt, want_vt)
+    # inside each 32-slot block: stored index 16*s2 + 8*h + 4*g + r holds slot 16*s2 + 8*g + 4*h + r
+    st = torch.arange(32)
+    src = 16 * (st >> 4) + 8 * ((st >> 2) & 1) + 4 * ((st >> 3) & 1) + (st & 3)
+    perm = (torch.arange(batch.t_pad).view(-1, 32)[:, :1] + src.view(1, 32)).reshape(-1).to(DEV)
+    assert torch.equal(vt, want_vt[:, :, perm])
     out = torch.empty(t, hq * 128, dtype=BF, device=DEV)
     ops.attention(qkv, vt, out, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
     f = qkv[:t].float().cpu()
