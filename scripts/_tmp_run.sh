@@ -1,6 +1,5 @@
 set -e
-timeout -k 10 900 python -m pytest tests/test_encoder_gpu.py -x -q 2>&1 | tail -3
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/attn -- python3 scripts/dev_encode_bench.py > gpurun_out/attn_out.txt 2>&1 || true
-python scripts/pmc_summary.py stats gpurun_out/attn gpurun_out/attn_kernel_stats.csv
-find gpurun_out/attn -name "*kernel_trace.csv" -delete
-head -6 gpurun_out/attn_kernel_stats.csv | cut -c1-150
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+CRAG_BENCH_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline --encode-steps 1 2>gpurun_out/n2.err | tail -1 | cut -c1-900
+for nq in 128 256; do ROWS=100000 NQ=$nq K=10 python scripts/dev_time.py; done
+ROWS=100000 NQ=64 K=50 python scripts/dev_time.py
