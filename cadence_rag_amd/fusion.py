@@ -99,3 +99,47 @@ class TechTokenIndex:
                                          self._bitmap.data_ptr(), out_ids.data_ptr(), out_ct.data_ptr(),
                                          ctypes.c_void_p(stream)), "crag_tech_lane")
         return out_ids, out_ct
+
+
+# ------------------------------------------------------------------------------------------------
+# batched hybrid retrieve (BASELINE configs[4]): dense + exact-token + given BM25 lanes -> RRF, on the GPU
+# ------------------------------------------------------------------------------------------------
+class HybridSearcher:
+    """The candidate stage of retrieve_evidence (/root/reference/app/retrieve.py:437-545) for a BATCH of up
+    to 64 queries over one table, with every lane and the fusion on the device and no host round trip in
+    between: dense top-`dense_k` (exact cosine scan), exact-token top-`tech_k`, caller-supplied BM25 ids
+    (pg_search's ranking is an input, as it is to _rrf_merge), fused by reciprocal rank in the reference's
+    lane order bm25 -> tech_tokens -> dense."""
+
+    def __init__(self, index, tech_index: "TechTokenIndex | None" = None, *, dense_k: int = 50, tech_k: int = 50,
+                 rrf_k: int = DEFAULT_RRF_K) -> None:
+        self.index, self.tech = index, tech_index
+        self.dense_k, self.tech_k, self.rrf_k = int(dense_k), int(tech_k), int(rrf_k)
+        self._dense_out = None
+
+    def search(self, query_vectors: torch.Tensor, query_token_lists=None, bm25=None, *, out_k: int = 0,
+               row_mask=None, mask_stride: int = 0, stream: int = 0) -> Dict[str, torch.Tensor]:
+        """query_vectors [nq, dim] fp32 CUDA; query_token_lists: per query its extract_tech_tokens();
+        bm25: (ids int64 [nq, w] CUDA, counts int32 [nq] CUDA) or None; row_mask: packed bits per row
+        position (uint8 CUDA), shared (mask_stride 0) or per query.  Returns rrf_fuse's dict plus the dense
+        lane itself ("dense_ids", "dense_scores", "dense_counts")."""
+        nq = int(query_vectors.shape[0])
+        dev = query_vectors.device
+        if self._dense_out is None or self._dense_out[0].shape != (nq, self.dense_k):
+            self._dense_out = (torch.empty(nq, self.dense_k, dtype=torch.int64, device=dev),
+                               torch.empty(nq, self.dense_k, dtype=torch.float32, device=dev),
+                               torch.empty(nq, dtype=torch.int32, device=dev))
+        d_ids, d_sc, d_ct = self._dense_out
+        self.index.search_async(query_vectors, self.dense_k, d_ids, d_sc, d_ct, d_row_mask=row_mask,
+                                mask_stride=mask_stride, stream=stream)
+        lanes = []
+        if bm25 is not None:
+            lanes.append(bm25)
+        if self.tech is not None and query_token_lists is not None:
+            lanes.append(self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
+                                          stream=stream))
+        lanes.append((d_ids, d_ct))
+        width = sum(int(t.shape[1]) for t, _ in lanes)
+        out = rrf_fuse(lanes, out_k=out_k or width, rrf_k=self.rrf_k, stream=stream)
+        out["dense_ids"], out["dense_scores"], out["dense_counts"] = d_ids, d_sc, d_ct
+        return out

@@ -5,7 +5,7 @@ import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from cadence_rag_amd.dense_index import DenseIndex
-from cadence_rag_amd.fusion import TechTokenIndex, rrf_fuse
+from cadence_rag_amd.fusion import HybridSearcher, TechTokenIndex, rrf_fuse
 
 rows = int(os.environ.get("ROWS", 1_000_000)); nq = 64
 dev = torch.device("cuda", 0)
@@ -26,10 +26,10 @@ bm25_ct = torch.full((nq,), 50, dtype=torch.int32, device=dev)
 d_ids = torch.empty(nq, 100, dtype=torch.int64, device=dev); d_sc = torch.empty(nq, 100, device=dev); d_ct = torch.empty(nq, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 
+hybrid = HybridSearcher(index, tech, dense_k=100, tech_k=50)
+
 def step():
-    index.search_async(q, 100, d_ids, d_sc, d_ct, stream=st)
-    t_ids, t_ct = tech.search(qtoks, 50, stream=st)
-    return rrf_fuse([(bm25_ids, bm25_ct), (t_ids, t_ct), (d_ids, d_ct)], out_k=200, stream=st)
+    return hybrid.search(q, qtoks, (bm25_ids, bm25_ct), out_k=200, stream=st)
 
 for _ in range(3): out = step()
 torch.cuda.synchronize(); n = 20; t0 = time.perf_counter()

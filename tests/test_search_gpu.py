@@ -502,3 +502,51 @@ def test_retrieve_evidence_over_gpu_backend_matches_cpu_composition(gpu, monkeyp
                 assert got["notes"]["retrieval"]["lanes"] == {"bm25": True, "tech_tokens": True, "dense": True}
     finally:
         chunks.close(); arts.close()
+
+
+def test_hybrid_searcher_batch_matches_python_rrf(gpu):
+    """HybridSearcher (dense + token lane + given BM25 -> RRF, all on the GPU) against the oracle's dense
+    order, a Python token filter and the host mirror of _rrf_merge, incl. a per-query row mask."""
+    import torch
+    from cadence_rag_amd.fusion import HybridSearcher, TechTokenIndex
+    rng = np.random.default_rng(321)
+    n, nq = 3000, 37
+    corpus = unit_rows(rng, n)
+    vocab = ["T-%d" % i for i in range(40)]
+    row_tokens = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(n)]
+    ids = np.arange(n, dtype=np.int64) + 500
+    started = np.datetime64("2026-02-01", "us") + rng.integers(0, 30, size=n).astype("timedelta64[D]")
+    qvec = rng.standard_normal((nq, 1024)).astype(np.float32)
+    qtoks = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(nq)]
+    bm25 = np.stack([rng.choice(ids, size=20, replace=False) for _ in range(nq)])
+    bm25_ct = rng.integers(0, 21, size=nq).astype(np.int32)
+    elig = rng.random((nq, n)) < 0.6
+    dev = torch.device("cuda", 0)
+    index = DenseIndex(1024, capacity=n)
+    try:
+        index.add(corpus, ids=ids)
+        tech = TechTokenIndex(row_tokens, ids, started, dev)
+        hs = HybridSearcher(index, tech, dense_k=40, tech_k=15)
+        packed = DenseIndex.pack_mask(elig)
+        d_mask = torch.from_numpy(packed).to(dev)
+        out = hs.search(torch.from_numpy(qvec).to(dev), qtoks,
+                        (torch.from_numpy(bm25).to(dev), torch.from_numpy(bm25_ct).to(dev)),
+                        row_mask=d_mask, mask_stride=packed.shape[1])
+        torch.cuda.synchronize()
+        got_ids, got_ct = out["ids"].cpu().numpy(), out["counts"].cpu().numpy()
+        got_sc, got_lanes = out["scores"].cpu().numpy(), out["lanes"].cpu().numpy()
+        want_dense = oracle.exact_topk(qvec, corpus, 40, mask=np.packbits(elig, axis=-1, bitorder="little"), mode=oracle.F64)
+        for qi in range(nq):
+            dense_rows = [{"id": int(ids[p])} for p in want_dense[0][qi, :want_dense[2][qi]]]
+            hits = [i for i in range(n) if elig[qi, i] and set(qtoks[qi]) & set(row_tokens[i])]
+            hits.sort(key=lambda i: (-started[i].astype(np.int64), ids[i]))
+            tech_rows = [{"id": int(ids[i])} for i in hits[:15]]
+            bm_rows = [{"id": int(v)} for v in bm25[qi, :bm25_ct[qi]]]
+            want = rt._rrf_merge({"bm25": bm_rows, "tech_tokens": tech_rows, "dense": dense_rows}, "id")
+            assert got_ct[qi] == len(want)
+            assert got_ids[qi, :len(want)].tolist() == [row["id"] for row, _, _ in want]
+            assert np.array_equal(got_sc[qi, :len(want)], np.array([s for _, _, s in want]))
+            lane_bits = {"bm25": 1, "tech_tokens": 2, "dense": 4}
+            assert got_lanes[qi, :len(want)].tolist() == [sum(lane_bits[l] for l in lanes) for _, lanes, _ in want]
+    finally:
+        index.close()
