@@ -1034,7 +1034,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
     // second barrier (single-buffered slab only) after op 3 of the last query block
     constexpr int LOADS = NQB == 2 ? 81 : 41;
     constexpr int TINFO = SLOTS - 1 - 2 * (2 * NQB - 1);  // 121 / 61
-    constexpr int BAR2 = 2 * (PIPE_OPS + 4) + 1;
+    // NQB = 2: the slab writes are software-pipelined too.  Block 0's accumulator is complete after slot 119
+    // and goes to the slab in the odd slots 121..127 (under block 1's last run); block 1's is written in slots
+    // 1..7 of the NEXT tile (under block 0's first run, which starts from C = 0), so the matrix pipe never waits
+    // for the accumulator -> LDS hand-over.  The background ops therefore start OPS0 slots into the tile.
+    constexpr int OPS0 = NQB == 2 ? 10 : 0;
+    constexpr int BAR2 = OPS0 + 2 * (PIPE_OPS + 4) + 1;
+    const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) acc[qb] = zero16;
 
     for (int ti = 0; ti < c.n_tiles; ++ti) {
         const uint32_t vnext = tile_voff(c, ti + 1);
@@ -1050,9 +1059,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
         cur_nrow = ~(uint32_t)row;
         const int rbuf = NQB == 2 ? 0 : (wbuf ^ 1);
 
-        f32x16 acc[NQB];
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) acc[qb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         static_for<0, SLOTS>([&](auto M) {
             constexpr int m = decltype(M)::value;
             if constexpr (NQB == 2) {
@@ -1060,7 +1066,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 // accumulator costs the matrix pipe ~15 cycles, so each accumulator is kept for runs of 8.
                 constexpr int grp = m >> 4, r16 = m & 15, qb = r16 >> 3, s = 2 * grp + ((r16 >> 2) & 1), cc = r16 & 3,
                               slot = s & 7;
-                acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
+                if constexpr (m == 0 || m == 8) acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], zero16);  // first of the tile
+                else acc[qb] = CRAG_MFMA(a[qb][s][cc], b[slot][cc], acc[qb]);
+                if constexpr ((m & 1) == 1 && m < 8) {  // block 1 of the PREVIOUS tile -> slab (see OPS0)
+                    constexpr int i = m >> 1;
+                    L.slab[0][w][1][2 * i][lane] = make_float2(acc[1][4 * i], acc[1][4 * i + 1]);
+                    L.slab[0][w][1][2 * i + 1][lane] = make_float2(acc[1][4 * i + 2], acc[1][4 * i + 3]);
+                }
+                if constexpr ((m & 1) == 1 && m >= 121) {  // block 0 of THIS tile -> slab, after the second barrier
+                    constexpr int i = (m - 121) >> 1;
+                    L.slab[0][w][0][2 * i][lane] = make_float2(acc[0][4 * i], acc[0][4 * i + 1]);
+                    L.slab[0][w][0][2 * i + 1][lane] = make_float2(acc[0][4 * i + 2], acc[0][4 * i + 3]);
+                }
                 if constexpr (r16 == 15) {  // both ring slots of the group consumed: refill for steps +8
 #pragma unroll
                     for (int ds = 0; ds < 2; ++ds) {
@@ -1072,15 +1089,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 }
             } else {
                 constexpr int s = m >> 2, cc = m & 3;
-                acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], acc[0]);
+                if constexpr (m == 0) acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], zero16);
+                else acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], acc[0]);
                 if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
             }
-            if constexpr ((m & 1) == 0) {
-                constexpr int o = m >> 1;
+            if constexpr ((m & 1) == 0 && m >= OPS0) {
+                constexpr int o = (m - OPS0) >> 1;
                 if constexpr (o < PIPE_OPS) pipe2_bg<o, 0, NQB, KS>(p, c, c2, L, rbuf, st);
                 else if constexpr (NQB == 2 && o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, NQB - 1, NQB, KS>(p, c, c2, L, rbuf, st);
             }
-            if constexpr (m == 3) {
+            if constexpr (m == OPS0 + 3) {
                 // first tile only: the query norms (partials were written before barrier 0)
                 if (ti == 0) {
 #pragma unroll
@@ -1132,16 +1150,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        const int sbuf = NQB == 2 ? 0 : wbuf;
+        if constexpr (NQB == 1) {
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-            for (int pr = 0; pr < 8; ++pr) L.slab[sbuf][w][qb][pr][lane] = make_float2(acc[qb][2 * pr], acc[qb][2 * pr + 1]);
+            for (int pr = 0; pr < 8; ++pr) L.slab[wbuf][w][0][pr][lane] = make_float2(acc[0][2 * pr], acc[0][2 * pr + 1]);
+        }
         wbuf ^= 1;
         vcur = vnext;
     }
     st.nrow = cur_nrow;
     if (c.n_tiles > 0) {  // drain: epilogue of the last tile
+        if constexpr (NQB == 2) {  // its block-1 accumulator is still in registers
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) L.slab[0][w][1][pr][lane] = make_float2(acc[1][2 * pr], acc[1][2 * pr + 1]);
+        }
         const int rbuf = NQB == 2 ? 0 : (wbuf ^ 1);
         static_for<0, PIPE_OPS>([&](auto O) { pipe2_bg<decltype(O)::value, 0, NQB, KS>(p, c, c2, L, rbuf, st); });
         if constexpr (NQB == 2)
