@@ -326,7 +326,7 @@ def main() -> None:
         if encode is not None:
             line["encode"] = encode
             line["config"]["encode"] = "see top-level 'encode' (chunks embedded/sec, BASELINE configs[3] shape)"
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores)
             # rank 0's own shard result (before the cross-shard merge) vs the oracle on that shard
             base, recall, same_order = cpu_baseline(corpus.cpu().numpy(), queries.cpu().numpy(),
                                                     out_ids.cpu().numpy())

@@ -101,6 +101,9 @@ class PackedBatch:
                            dev(blk_seq[order]), dev(blk_q0[order]))
 
 
+QKV_ROW_CHUNK = 32768
+
+
 class Qwen3Encoder:
     """Weights live as bf16 CUDA tensors; `layers[i]` holds the fused projections."""
 
@@ -221,7 +224,11 @@ class Qwen3Encoder:
                 resid.copy_(x)
             else:
                 ops.rmsnorm(delta, L["ln1"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
-            torch.matmul(normed, L["qkv"].t(), out=qkv)
+            # hipBLASLt picks a ~13 % faster kernel for this shape (K 2560, N 6144) at M = 32768 than at 65536
+            # (scripts/probes/gemm_layouts.py), so large batches run the projection in row chunks
+            for lo in range(0, t, QKV_ROW_CHUNK):
+                hi = min(t, lo + QKV_ROW_CHUNK)
+                torch.matmul(normed[lo:hi], L["qkv"].t(), out=qkv[lo:hi])
             ops.qk_norm_rope(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
                              c.num_heads, c.num_kv_heads, c.rms_norm_eps)
             ops.v_transpose(qkv_buf, vt, batch.tok_of_pad, c.num_heads, c.num_kv_heads)
