@@ -2,17 +2,22 @@
 EMBEDDINGS_BASE_URL at the MI355X box: `POST /embed {texts, model?} -> {embeddings, model}` and
 `GET /health` (/root/reference/P620_TRITON_QWEN3_4B_EMBEDDING_RUNBOOK.md:489-497,669-716).
 The body is served by the in-process encoder registered with embeddings.set_encoder().
+`POST /retrieve` is the reference's own route (/root/reference/app/main.py:184-186) over
+retrieve.retrieve_evidence and the backend registered with retrieve.set_backend().
 
     uvicorn cadence_rag_amd.gateway:app --host 0.0.0.0 --port 8100
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from datetime import datetime
+from typing import List, Literal, Optional
+from uuid import UUID
 
 from fastapi import FastAPI, HTTPException
 from pydantic import BaseModel, Field
 
 from . import embeddings
+from . import retrieve as _retrieve
 from .config import settings
 
 
@@ -55,3 +60,41 @@ def embed(req: EmbedRequest) -> EmbedResponse:
         raise HTTPException(status_code=502, detail=f"encoder returned vectors of the wrong size "
                                                     f"(expected {settings.embeddings_dim})")
     return EmbedResponse(embeddings=vectors, model=req.model or model)
+
+
+# ---- POST /retrieve: request models field-for-field app/schemas.py:71-93 -------------------------
+class BudgetModel(BaseModel):
+    max_evidence_items: int = 8
+    max_total_chars: int = 6000
+
+
+class RetrieveFiltersModel(BaseModel):
+    date_from: Optional[datetime] = None
+    date_to: Optional[datetime] = None
+    call_ids: Optional[List[UUID]] = None
+    external_id: Optional[str] = None
+    external_source: Optional[str] = None
+    call_tags: Optional[List[str]] = None
+
+
+class RetrieveRequestModel(BaseModel):
+    query: str
+    intent: Literal["auto", "decision", "action_items", "who_said", "troubleshooting", "status"] = "auto"
+    filters: Optional[RetrieveFiltersModel] = None
+    budget: BudgetModel = Field(default_factory=BudgetModel)
+    return_style: Literal["evidence_pack_json", "ids_only"] = "evidence_pack_json"
+    debug: bool = False
+
+
+@app.post("/retrieve")
+def retrieve_endpoint(payload: RetrieveRequestModel) -> dict:
+    filters = None
+    if payload.filters is not None:
+        filters = _retrieve.RetrieveFilters(**payload.filters.model_dump())
+    request = _retrieve.RetrieveRequest(
+        query=payload.query, intent=payload.intent, filters=filters,
+        budget=_retrieve.Budget(**payload.budget.model_dump()), return_style=payload.return_style, debug=payload.debug)
+    try:
+        return _retrieve.retrieve_evidence(request)
+    except RuntimeError as exc:  # no backend registered
+        raise HTTPException(status_code=503, detail=str(exc)) from exc
