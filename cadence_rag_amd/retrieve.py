@@ -194,6 +194,46 @@ class DenseTable:
             rows.append(row)
         return rows
 
+    @classmethod
+    def from_rows(cls, name: str, id_field: str, rows, *, select: Sequence[str], dim: Optional[int] = None,
+                  call_tags: Optional[Dict[Any, Sequence[str]]] = None, batch: int = 65536,
+                  device: Optional[int] = None) -> Tuple["DenseTable", List[List[str]]]:
+        """Startup loader: `rows` are the mappings of
+            SELECT <select>, call_started_at, tech_tokens, embedding FROM <name>
+            WHERE embedding IS NOT NULL ORDER BY <id_field>
+        with `embedding` in any of pgvector's forms (text literal '[v,...]', binary send/recv bytes, or a
+        sequence of floats).  Returns the table and the per-row tech_tokens (for build_tech_lane).  Rows must
+        come in ascending id order so that equal scores resolve to the lower id, as ORDER BY does."""
+        from . import vector_io
+        rows = list(rows)
+        d = dim or settings.embeddings_dim
+        table = cls(name, id_field, dim=d, capacity=max(len(rows), 1), device=device)
+        tokens: List[List[str]] = []
+        last_id = None
+        for lo in range(0, len(rows), batch):
+            part = rows[lo:lo + batch]
+            vecs = np.empty((len(part), d), dtype=np.float32)
+            for i, row in enumerate(part):
+                emb = row["embedding"]
+                if isinstance(emb, str):
+                    vecs[i] = vector_io.parse_vector(emb, d)
+                elif isinstance(emb, (bytes, bytearray, memoryview)):
+                    v = vector_io.from_binary(bytes(emb))
+                    if v.size != d:
+                        raise ValueError(f"expected {d} dimensions, not {v.size}")
+                    vecs[i] = v
+                else:
+                    vecs[i] = np.asarray(emb, dtype=np.float32).reshape(d)
+                rid = row[id_field]
+                if last_id is not None and rid <= last_id:
+                    raise ValueError(f"rows must be in ascending {id_field} order ({rid} after {last_id})")
+                last_id = rid
+                tokens.append(list(row.get("tech_tokens") or []))
+            cols = {c: [row[c] for row in part] for c in select}
+            table.add(vecs, cols, call_started_at=[row.get("call_started_at") for row in part],
+                      call_tags=call_tags if lo == 0 else None)
+        return table, tokens
+
     def build_tech_lane(self, row_tokens: Sequence[Sequence[str]]):
         """GPU exact-token lane over this table's rows (row i <-> position i, so filter masks are shared):
         the `tech_tokens text[]` column + ORDER BY call_started_at DESC, id ASC (retrieve.py:183-242)."""

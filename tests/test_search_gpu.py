@@ -573,3 +573,33 @@ def test_pipelined_and_unpipelined_kernels_agree(gpu, monkeypatch, n, nq, k):
         assert_topk_matches(a[0], a[1], a[2], b[0], b[1].astype(np.float64), b[2], tol=2e-7, gap=2e-6)
     finally:
         index.close()
+
+
+def test_dense_table_loader_accepts_pgvector_text_and_binary(gpu):
+    """DenseTable.from_rows: the startup load of `SELECT ..., embedding FROM chunks WHERE embedding IS NOT NULL`
+    with embeddings as text literals, pgvector binary and float lists; round-trips bit-exactly."""
+    from datetime import datetime
+    from uuid import UUID
+
+    from cadence_rag_amd import vector_io
+    rng = np.random.default_rng(12)
+    n = 300
+    vecs = unit_rows(rng, n)
+    forms = [lambda v: rt._vector_literal(v.tolist()), lambda v: vector_io.to_binary(v), lambda v: v.tolist()]
+    rows = [{"chunk_id": 10 + i, "call_id": UUID(int=1 + i % 3), "speaker": "S", "start_ts_ms": i, "end_ts_ms": i + 1,
+             "text": f"t{i}", "call_started_at": datetime(2026, 1, 1 + i % 5), "tech_tokens": ["X-1"] if i % 7 == 0 else [],
+             "embedding": forms[i % 3](vecs[i])} for i in range(n)]
+    table, tokens = rt.DenseTable.from_rows("chunks", "chunk_id", rows, select=rt.CHUNK_SELECT, dim=1024, batch=128)
+    try:
+        assert len(table) == n and tokens[7] == ["X-1"] and tokens[1] == []
+        back, back_ids = table.index.get_rows(0, n)
+        assert np.array_equal(back, vecs) and back_ids.tolist() == list(range(10, 10 + n))  # '.10g' text and big-endian float4 both round-trip float32
+        got = rt._fetch_chunks_dense(table, vecs[123], None, None, "exact", 3)
+        assert got[0]["chunk_id"] == 133 and got[0]["text"] == "t123"
+        lane = table.build_tech_lane(tokens)
+        ids, ct = lane.search([["X-1"]], 5)
+        assert int(ct[0]) == 5
+        with pytest.raises(ValueError, match="ascending"):
+            rt.DenseTable.from_rows("chunks", "chunk_id", rows[::-1][:2], select=rt.CHUNK_SELECT, dim=1024)[0].close()
+    finally:
+        table.close()
