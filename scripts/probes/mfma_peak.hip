@@ -6,15 +6,25 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(512) void probe(float *out, unsigned long long *clk, int iters, float seed) {
+// `random` = 1: operands are 16 different pseudo-random values per lane (data toggling as in a real scan);
+// 0: the same two values throughout (the low-power case)
+__global__ __launch_bounds__(512) void probe(float *out, unsigned long long *clk, int iters, float seed, int random) {
     f32x16 acc0 = {0}, acc1 = {0};
-    float a = seed + threadIdx.x, b = seed * 0.5f;
+    float av[8], bv[8];
+    unsigned rs = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        rs = rs * 1664525u + 1013904223u;
+        av[r] = random ? ((int)(rs >> 8) - (1 << 23)) * (1.0f / (1 << 23)) * 0.03f : seed + threadIdx.x;
+        rs = rs * 1664525u + 1013904223u;
+        bv[r] = random ? ((int)(rs >> 8) - (1 << 23)) * (1.0f / (1 << 23)) * 0.03f : seed * 0.5f;
+    }
     const unsigned long long c0 = clock64(), w0 = wall_clock64();
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+        for (int r = 0; r < 8; ++r) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], bv[r], acc0, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+        for (int r = 0; r < 8; ++r) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[r], av[7 - r], acc1, 0, 0, 0);
     }
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
     float s = 0.f;
@@ -35,11 +45,13 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
+    for (int random : {0, 1})
     for (int iters : {2000, 20000, 200000}) {
-        hipLaunchKernelGGL(probe, dim3(G), dim3(T), 0, 0, out, clk, iters, 1.0f);
+        printf("%s operands: ", random ? "random" : "constant");
+        hipLaunchKernelGGL(probe, dim3(G), dim3(T), 0, 0, out, clk, iters, 1.0f, random);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(probe, dim3(G), dim3(T), 0, 0, out, clk, iters, 1.0f);
+        hipLaunchKernelGGL(probe, dim3(G), dim3(T), 0, 0, out, clk, iters, 1.0f, random);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
