@@ -1,7 +1,7 @@
 """Developer check: HIP search vs the CPU oracle on seeded inputs (run on the GPU box)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # repo root
 import oracle
 from cadence_rag_amd.dense_index import DenseIndex
 
