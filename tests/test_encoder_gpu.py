@@ -100,7 +100,7 @@ def _attn_ref(q, k, v, lens, hq, hkv):
 
 
 @pytest.mark.parametrize("lens,hq,hkv", [([1], 4, 1), ([31, 32, 33], 4, 2), ([5, 200, 64, 1, 97], 8, 2),
-                                         ([300, 17], 32, 8)])
+                                         ([300, 17], 32, 8), ([40, 3, 130], 2, 2), ([70, 33], 8, 1)])
 def test_v_transpose_and_attention(gpu, lens, hq, hkv):
     from cadence_rag_amd.encoder import ops
     from cadence_rag_amd.encoder.qwen3 import PackedBatch
