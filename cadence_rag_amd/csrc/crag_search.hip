@@ -584,6 +584,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t gb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.gbound, 0, (int)((uint32_t)gridDim.y * 32u * GB_CELLS * 4u), 0x00020000);
     u32x4 b[16];
     {
         const uint32_t v0 = tile_voff(c, 0);
@@ -655,11 +657,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
         // in the final top-k.  Stale values only prune less.
         uint32_t gbv[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-            gbv[e] = (j < p.k && c.qok[e])
-                         ? __hip_atomic_load(p.gbound + (size_t)(c.qb * 32 + c.qloc[e]) * GB_CELLS + j,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : 0xffffffffu;
+        for (int e = 0; e < 2; ++e) {
+            // plain cached load on purpose (see scan_pipe2_kernel): stale values only prune less
+            uint32_t off = (j < p.k && c.qok[e]) ? (uint32_t)((c.qb * 32 + c.qloc[e]) * GB_CELLS + j) * 4u : 0x80000000u;
+            asm volatile("" : "+v"(off));  // opaque: the load must be re-issued every tile
+            const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(gb_rsrc, off, 0, 0);
+            gbv[e] = (off == 0x80000000u) ? 0xffffffffu : v;
+        }
         PipeTile cur;
         cur.nrow = ~(uint32_t)row;
         cur.scale[0] = cur.scale[1] = 0.f;
