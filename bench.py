@@ -165,9 +165,10 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int):
         "model": "Qwen3-Embedding-4B architecture (36L, 2560h, 32q/8kv x128, 9728 ffn), seeded random weights",
         "pooling": "last token -> [:1024] -> L2 normalise", "parallelism": "replicas" if world > 1 else "1 GPU",
         "outputs_unit_norm": ok,
-        "roofline": {"bound": "mfma", "achieved": round(tflops / world, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                     "frac": round(tflops / world / 2500.0, 4), "traffic": None,
-                     "note": "whole forward (library GEMMs + HIP ops), algorithmic FLOPs 2*P + causal attention"},
+        # per GPU: `tflops` is this rank's own batch over the slowest rank's time
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(tflops / 2500.0, 4), "traffic": None,
+                     "note": "per GPU; whole forward (library GEMMs + HIP ops), algorithmic FLOPs 2*P + causal attention"},
     }
 
 
