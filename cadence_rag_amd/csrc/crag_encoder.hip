@@ -351,7 +351,10 @@ void attention_kernel(AttnParams p) {
             sv[i] = v;
             mloc = fmaxf(mloc, v);
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        {  // combine the two half-waves (keys 4h..): v_permlane32_swap instead of an LDS-crossbar shuffle
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+            mloc = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        }
         const float mnew = fmaxf(m, mloc);  // finite: key k0 (<= q0 + c) is never masked
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         float lsum = 0.f;
@@ -360,7 +363,10 @@ void attention_kernel(AttnParams p) {
             sv[i] = __builtin_amdgcn_exp2f(sv[i] - mnew);
             lsum += sv[i];
         }
-        lsum += __shfl_xor(lsum, 32);
+        {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+            lsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
         l = l * alpha + lsum;
         if (__any(mnew != m)) {  // wave-uniform: once the running maxima have settled no rescale is needed
 #pragma unroll
