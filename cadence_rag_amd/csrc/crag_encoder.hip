@@ -9,6 +9,8 @@
 // transformers' Qwen3Model in tests/test_encoder_gpu.py).
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -262,10 +264,12 @@ void attention_kernel(AttnParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const int kvh = blockIdx.y;
+    // kv head on the fast grid axis: workgroups go to the 8 XCDs round-robin by linear id, so with 8 kv heads
+    // every XCD serves ONE kv head and the q blocks that re-read a sequence's K/V tiles share that XCD's L2
+    const int kvh = blockIdx.x;
     const int head = kvh * GROUP + wave;  // GROUP = query heads per kv head = waves per workgroup
-    const int seq = p.blk_seq[blockIdx.x];
-    const int q0 = p.blk_q0[blockIdx.x];
+    const int seq = p.blk_seq[blockIdx.y];
+    const int q0 = p.blk_q0[blockIdx.y];
     const int s_begin = p.cu[seq];
     const int len = p.cu[seq + 1] - s_begin;
     const int64_t pad_base = p.cu_pad[seq];
@@ -391,6 +395,206 @@ void attention_kernel(AttnParams p) {
         __syncthreads();
     }
     // O[q0 + c][32 dt + (i&3) + 8 (i>>2) + 4h] = oacc[dt][i] / l : 4 consecutive d per register quad
+    if (q0 + c < len) {
+        const float inv = 1.f / l;
+        u16 *op = p.out + (int64_t)(s_begin + q0 + c) * ((int64_t)p.hq * CRAG_HEAD_DIM) +
+                  (int64_t)head * CRAG_HEAD_DIM + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = (uint32_t)f2bf(oacc[dt][4 * g4] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 1] * inv) << 16);
+                w.y = (uint32_t)f2bf(oacc[dt][4 * g4 + 2] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 3] * inv) << 16);
+                *reinterpret_cast<uint2 *>(op + 32 * dt + 8 * g4) = w;
+            }
+    }
+}
+
+// ---- 64 keys per iteration (GROUP >= 4): two 32-key tiles share one softmax update, one barrier and one
+// staging round, and their QK chains interleave.  A q block with an odd number of key tiles ends with a
+// half pair (HALF): only its first tile exists (its second would lie entirely above the diagonal). ----
+constexpr int ATT_VROW2 = 72;  // u16 per staged V^T row of a pair (64 + 8 pad: conflict-free b128 reads)
+
+template <int GROUP>
+__global__ __launch_bounds__(64 * GROUP) __attribute__((amdgpu_waves_per_eu(2, 8)))
+void attention_pair_kernel(AttnParams p) {
+    static_assert(GROUP >= 4, "staging is sized for at least 256 threads");
+    __shared__ __attribute__((aligned(16))) u16 s_k[2][64 * ATT_KROW];
+    __shared__ __attribute__((aligned(16))) u16 s_v[2][CRAG_HEAD_DIM * ATT_VROW2];
+    constexpr int nthr = 64 * GROUP;
+    constexpr int per = 1024 / nthr;  // 16-byte chunks of K and of V^T per thread and pair
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    // kv head on the fast grid axis: workgroups go to the 8 XCDs round-robin by linear id, so with 8 kv heads
+    // every XCD serves ONE kv head and the q blocks that re-read a sequence's K/V tiles share that XCD's L2
+    const int kvh = blockIdx.x;
+    const int head = kvh * GROUP + wave;
+    const int seq = p.blk_seq[blockIdx.y];
+    const int q0 = p.blk_q0[blockIdx.y];
+    const int s_begin = p.cu[seq];
+    const int len = p.cu[seq + 1] - s_begin;
+    const int64_t pad_base = p.cu_pad[seq];
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t row_stride = (int64_t)(p.hq + 2 * p.hkv) * CRAG_HEAD_DIM;
+
+    bf16x8 qf[8];
+    {
+        const u16 *qp = p.qkv + (int64_t)(s_begin + q0 + c) * row_stride + (int64_t)head * CRAG_HEAD_DIM + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = ld_frag(qp + 16 * s);
+    }
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 oacc[4] = {zero, zero, zero, zero};
+    float m = -INFINITY, l = 0.f;
+    const int n_kt = q0 / 32 + 1;          // 32-key tiles up to and including the diagonal one
+    const int n_pairs = (n_kt + 1) >> 1;
+    const bool last_half = (n_kt & 1) != 0;
+    const u16 *kglob = p.qkv + (int64_t)s_begin * row_stride + (int64_t)(p.hq + kvh) * CRAG_HEAD_DIM;
+    const u16 *vglob = p.vt + (int64_t)kvh * CRAG_HEAD_DIM * p.t_pad + pad_base;
+
+    struct Stage {
+        bf16x8 k[per], v[per];
+    };
+    // K pair: 64 rows x 16 chunks; V^T pair: 128 rows x 8 chunks.  A half pair moves only the first tile.
+    // per-thread bases computed once; chunk i and pair pr only add wave-uniform offsets
+    const u16 *kthr = kglob + (int64_t)(tid >> 4) * row_stride + 8 * (tid & 15);
+    const u16 *vthr = vglob + (int64_t)(tid >> 3) * p.t_pad + 8 * (tid & 7);
+    const int64_t kstep = (int64_t)(nthr >> 4) * row_stride, vstep = (int64_t)(nthr >> 3) * p.t_pad;
+    auto fetch = [&](int pr, bool half, Stage &st) {
+        const u16 *kp = kthr + (int64_t)(pr * 64) * row_stride;
+        const u16 *vp = vthr + pr * 64;
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            // K rows (tid >> 4) + i * nthr / 16: the second tile's rows are i >= per / 2; V^T columns 8 * (tid & 7)
+            if (!(half && i >= per / 2)) st.k[i] = ld_frag(kp + i * kstep);
+            if (!(half && (tid & 7) >= 4)) st.v[i] = ld_frag(vp + i * vstep);
+        }
+    };
+    auto stash = [&](int buf, const Stage &st) {
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int ch = tid + i * nthr;
+            *reinterpret_cast<bf16x8 *>(&s_k[buf][(ch >> 4) * ATT_KROW + 8 * (ch & 15)]) = st.k[i];
+            *reinterpret_cast<bf16x8 *>(&s_v[buf][(ch >> 3) * ATT_VROW2 + 8 * (ch & 7)]) = st.v[i];
+        }
+    };
+    Stage st;
+#pragma unroll
+    for (int i = 0; i < per; ++i) st.k[i] = st.v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    fetch(0, n_pairs == 1 && last_half, st);
+    stash(0, st);
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // clean vmcnt scoreboard at the loop head (see attention_kernel)
+
+    // one pair of key tiles; HALF: only the first tile; DIAG: the pair's last existing tile is the diagonal one
+    auto pair = [&](int pr, auto HALF_, auto DIAG_) {
+        constexpr bool HALF = decltype(HALF_)::value, DIAG = decltype(DIAG_)::value;
+        const int k0 = pr * 64, buf = pr & 1;
+        if (pr + 1 < n_pairs) fetch(pr + 1, (pr + 2 == n_pairs) && last_half, st);
+        f32x16 sa = zero, sb = zero;
+        {
+            const u16 *kp = &s_k[buf][c * ATT_KROW + 8 * h];
+#pragma unroll
+            for (int half4 = 0; half4 < 2; ++half4) {  // 4 k-steps of both tiles per round: 8 fragments in flight
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    fa[s] = *reinterpret_cast<const bf16x8 *>(kp + 16 * (4 * half4 + s));
+                    if constexpr (!HALF) fb[s] = *reinterpret_cast<const bf16x8 *>(kp + 32 * ATT_KROW + 16 * (4 * half4 + s));
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], qf[4 * half4 + s], sa, 0, 0, 0);
+                    if constexpr (!HALF) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[s], qf[4 * half4 + s], sb, 0, 0, 0);
+                }
+            }
+        }
+        // V^T fragments of the first tile are requested now and arrive during the softmax
+        bf16x8 fv[8];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                fv[2 * dt + s2] = *reinterpret_cast<const bf16x8 *>(&s_v[buf][(32 * dt + c) * ATT_VROW2 + 8 * h + 16 * s2]);
+        __builtin_amdgcn_sched_barrier(0);
+        // lane: query row q0 + c; register i of tile t: key k0 + 32 t + (i&3) + 8*(i>>2) + 4h
+        // the softmax scale is positive, so the row maximum is taken on the raw scores and the scale is folded
+        // into the exponent's fma: p = exp2(s * scale - m), m = scale * max(s)
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (DIAG && HALF && key > q0 + c) sa[i] = -INFINITY;
+            mloc = fmaxf(mloc, sa[i]);
+            if constexpr (!HALF) {
+                if (DIAG && key + 32 > q0 + c) sb[i] = -INFINITY;
+                mloc = fmaxf(mloc, sb[i]);
+            }
+        }
+        {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+            mloc = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+        }
+        const float mnew = fmaxf(m, mloc * p.scale_log2);  // finite: key k0 (<= q0 + c) is never masked
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        float lsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sa[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sa[i], p.scale_log2, -mnew));
+            lsum += sa[i];
+            if constexpr (!HALF) {
+                sb[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sb[i], p.scale_log2, -mnew));
+                lsum += sb[i];
+            }
+        }
+        {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+            lsum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        l = l * alpha + lsum;
+        if (__any(mnew != m)) {  // wave-uniform: once the running maxima have settled no rescale is needed
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+        }
+        m = mnew;
+        bf16x8 pa[2], pb[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                pa[s2][jj] = (short)f2bf(sa[8 * s2 + jj]);
+                if constexpr (!HALF) pb[s2][jj] = (short)f2bf(sb[8 * s2 + jj]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)  // 4 independent accumulator chains
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[2 * dt + s2], pa[s2], oacc[dt], 0, 0, 0);
+        if constexpr (!HALF) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    fv[2 * dt + s2] = *reinterpret_cast<const bf16x8 *>(&s_v[buf][(32 * dt + c) * ATT_VROW2 + 8 * h + 32 + 16 * s2]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[2 * dt + s2], pb[s2], oacc[dt], 0, 0, 0);
+        }
+        if (pr + 1 < n_pairs) stash(buf ^ 1, st);  // that buffer was last read one barrier ago
+        __syncthreads();
+    };
+
+    for (int pr = 0; pr + 1 < n_pairs; ++pr) pair(pr, std::false_type{}, std::false_type{});
+    if (last_half) pair(n_pairs - 1, std::true_type{}, std::true_type{});
+    else pair(n_pairs - 1, std::false_type{}, std::true_type{});
+
     if (q0 + c < len) {
         const float inv = 1.f / l;
         u16 *op = p.out + (int64_t)(s_begin + q0 + c) * ((int64_t)p.hq * CRAG_HEAD_DIM) +
@@ -536,12 +740,16 @@ int crag_enc_attention(const uint16_t *qkv, const uint16_t *vt, uint16_t *out, c
     p.hq = hq;
     p.hkv = hkv;
     p.scale_log2 = scale * 1.4426950408889634f;
-    const dim3 grid((unsigned)n_blocks, (unsigned)hkv);
+    if (n_blocks > 65535 * 64) return efail("attention: too many q blocks (%d)", n_blocks);
+    const dim3 grid((unsigned)hkv, (unsigned)n_blocks);
     switch (hq / hkv) {
         case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, p); break;
         case 2: hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, (hipStream_t)stream, p); break;
-        case 4: hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
-        default: hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
+        case 4:
+            if (getenv("CRAG_ATTN_SINGLE")) hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL(attention_pair_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+            break;
+        default: hipLaunchKernelGGL(attention_pair_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, p); break;
     }
     return hip_ok("attention");
 }
