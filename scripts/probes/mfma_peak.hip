@@ -3,6 +3,7 @@
 // accumulator).  hipcc --offload-arch=gfx950 -O3 mfma_peak.hip -o mfma_peak && ./mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -36,8 +37,9 @@ __global__ __launch_bounds__(512) void probe(float *out, unsigned long long *clk
     }
 }
 
-int main() {
-    const int G = 256, T = 512;
+int main(int argc, char **argv) {
+    const int G = 256;
+    const int T = argc > 1 ? atoi(argv[1]) : 512;  // 512 = 2 waves per SIMD, 256 = 1 wave per SIMD
     float *out;
     unsigned long long *clk;
     hipMalloc(&out, G * T * 4);
@@ -61,7 +63,7 @@ int main() {
         double cyc = 0, wall = 0;
         for (int g = 0; g < G; ++g) { cyc += h[2 * g]; wall += h[2 * g + 1]; }
         cyc /= G; wall /= G;
-        const double flop = (double)G * 8 /*waves*/ * iters * 16.0 * (32.0 * 32 * 2 * 2);
+        const double flop = (double)G * (T / 64) /*waves*/ * iters * 16.0 * (32.0 * 32 * 2 * 2);
         printf("iters=%d  kernel=%.3f ms  %.1f TFLOP/s  shader clock counter: %.0f ticks in %.0f x10ns -> %.3f ticks/ns;  "
                "MFMA cycles per instruction per SIMD (2 waves): %.1f ticks\n",
                iters, ms, flop / (ms * 1e-3) / 1e12, cyc, wall, cyc / (wall * 10.0), cyc / (iters * 16.0 * 2));
