@@ -253,10 +253,9 @@ __device__ __forceinline__ bf16x8 ld_frag(const u16 *p) { return *reinterpret_ca
 // their MFMA fragments from there (rows padded to 272 / 80 bytes: conflict-free ds_read_b128).
 constexpr int ATT_KROW = 136;   // u16 per staged K row (128 + 8 pad)
 constexpr int ATT_VROW = 40;    // u16 per staged V^T row (32 + 8 pad)
-constexpr int ATT_MAX_WAVES = 8;
 
 template <int GROUP>
-__global__ __launch_bounds__(64 * GROUP) __attribute__((amdgpu_waves_per_eu(2, 8)))
+__global__ __launch_bounds__(64 * GROUP) __attribute__((amdgpu_waves_per_eu(GROUP >= 2 ? 2 : 1, 8)))
 void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) u16 s_k[2][32 * ATT_KROW];
     __shared__ __attribute__((aligned(16))) u16 s_v[2][CRAG_HEAD_DIM * ATT_VROW];
