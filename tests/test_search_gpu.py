@@ -603,3 +603,27 @@ def test_dense_table_loader_accepts_pgvector_text_and_binary(gpu):
             rt.DenseTable.from_rows("chunks", "chunk_id", rows[::-1][:2], select=rt.CHUNK_SELECT, dim=1024)[0].close()
     finally:
         table.close()
+
+
+def test_property_random_shapes_masks_and_k(gpu):
+    """Property test over the whole kernel family (k <= 32 / 64 / 128, <= 32 / > 32 queries, ragged sizes,
+    zero rows, sparse and dense masks, small dims): every case must match the fp64 oracle."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @settings(max_examples=30, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+    @given(n=st.integers(1, 2500), nq=st.integers(1, 70), k=st.sampled_from([1, 3, 10, 32, 33, 50, 64, 100, 128]),
+           dim=st.sampled_from([1024, 1024, 1024, 384, 7]), mask_p=st.sampled_from([None, None, 0.0, 0.02, 0.5, 1.0]),
+           zero_rows=st.booleans(), seed=st.integers(0, 2 ** 16))
+    def run(n, nq, k, dim, mask_p, zero_rows, seed):
+        rng = np.random.default_rng(seed)
+        corpus = rng.standard_normal((n, dim)).astype(np.float32)
+        if zero_rows and n > 3:
+            corpus[rng.integers(0, n, size=2)] = 0.0
+        if n > 8:
+            corpus[n - 1] = corpus[1]  # an exact duplicate: tie broken by position
+        q = rng.standard_normal((nq, dim)).astype(np.float32)
+        mask = None if mask_p is None else (rng.random((nq, n)) < mask_p)
+        _check(corpus, q, k, mask=mask)
+
+    run()
