@@ -256,3 +256,36 @@ def test_packed_batch_equals_one_by_one_and_encoder_protocol(gpu, monkeypatch):
         assert np.allclose(res.vectors[0], batch_vecs[0], atol=1e-2)  # batch of 2 vs 3: other GEMM tiling
     finally:
         embeddings.set_encoder(None)
+
+
+def test_attention_property_random_lengths_and_groups(gpu):
+    """Random packed batches (ragged lengths around the 32/64-key tile boundaries) and GQA group sizes against
+    the fp32 reference: covers full pairs, half pairs and the diagonal tile in either half."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch
+
+    @settings(max_examples=12, deadline=None, derandomize=True,
+              suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+    @given(lens=st.lists(st.sampled_from([1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 129, 200]), min_size=1, max_size=4),
+           heads=st.sampled_from([(4, 1), (8, 2), (4, 4), (8, 1), (4, 2)]), seed=st.integers(0, 1000))
+    def run(lens, heads, seed):
+        hq, hkv = heads
+        g = torch.Generator().manual_seed(seed)
+        t = sum(lens)
+        qkv = torch.randn(t + 32, (hq + 2 * hkv) * 128, generator=g)
+        qkv[t:] = float("nan")
+        qkv = _bf(qkv)
+        batch = PackedBatch.build(lens, DEV)
+        vt = torch.empty(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+        ops.v_transpose(qkv, vt, batch.tok_of_pad, hq, hkv)
+        out = torch.full((t, hq * 128), float("nan"), dtype=BF, device=DEV)
+        ops.attention(qkv, vt, out, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
+        f = qkv[:t].float().cpu()
+        ref = _attn_ref(f[:, : hq * 128].view(t, hq, 128), f[:, hq * 128: (hq + hkv) * 128].view(t, hkv, 128),
+                        f[:, (hq + hkv) * 128:].view(t, hkv, 128), lens, hq, hkv)
+        got = out.float().cpu().view(t, hq, 128)
+        assert torch.isfinite(got).all()
+        assert torch.allclose(got, ref, atol=2e-2, rtol=2e-2), (lens, heads, (got - ref).abs().max())
+
+    run()
