@@ -257,8 +257,12 @@ constexpr int ATT_VROW = 40;    // u16 per staged V^T row (32 + 8 pad)
 template <int GROUP>
 __global__ __launch_bounds__(64 * GROUP) __attribute__((amdgpu_waves_per_eu(GROUP >= 2 ? 2 : 1, 8)))
 void attention_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) u16 s_k[2][32 * ATT_KROW];
-    __shared__ __attribute__((aligned(16))) u16 s_v[2][CRAG_HEAD_DIM * ATT_VROW];
+    // one pool: K buffers, then V^T buffers; the epilogue reuses its start for the per-wave output tiles
+    constexpr int K_BUF = 32 * ATT_KROW, V_BUF = CRAG_HEAD_DIM * ATT_VROW;
+    static_assert(GROUP * 32 * ATT_KROW <= 2 * (K_BUF + V_BUF) || GROUP > 4, "output tiles must fit the staging pool");
+    __shared__ __attribute__((aligned(16))) u16 s_pool[2 * (K_BUF + V_BUF)];
+    u16(*s_k)[K_BUF] = reinterpret_cast<u16(*)[K_BUF]>(s_pool);
+    u16(*s_v)[V_BUF] = reinterpret_cast<u16(*)[V_BUF]>(s_pool + 2 * K_BUF);
     constexpr int nthr = 64 * GROUP;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -394,10 +398,13 @@ void attention_kernel(AttnParams p) {
         __syncthreads();
     }
     // O[q0 + c][32 dt + (i&3) + 8 (i>>2) + 4h] = oacc[dt][i] / l : 4 consecutive d per register quad
-    if (q0 + c < len) {
+    // O[q0 + c][32 dt + (i&3) + 8 (i>>2) + 4h] = oacc[dt][i] / l.  Stored straight from these registers a wave
+    // instruction would write 16 bytes into each of 32 rows (partial lines: 40 % of the kernel's time at
+    // 256-token chunks); instead the wave transposes its 32 x 128 tile through LDS (the K staging buffer is free
+    // after the last barrier) and writes whole 256-byte rows, 16 bytes per lane.
+    {
+        u16 *ot = s_pool + wave * (32 * ATT_KROW);
         const float inv = 1.f / l;
-        u16 *op = p.out + (int64_t)(s_begin + q0 + c) * ((int64_t)p.hq * CRAG_HEAD_DIM) +
-                  (int64_t)head * CRAG_HEAD_DIM + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -405,8 +412,17 @@ void attention_kernel(AttnParams p) {
                 uint2 w;
                 w.x = (uint32_t)f2bf(oacc[dt][4 * g4] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 1] * inv) << 16);
                 w.y = (uint32_t)f2bf(oacc[dt][4 * g4 + 2] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 3] * inv) << 16);
-                *reinterpret_cast<uint2 *>(op + 32 * dt + 8 * g4) = w;
+                *reinterpret_cast<uint2 *>(ot + c * ATT_KROW + 32 * dt + 8 * g4 + 4 * h) = w;
             }
+        // same wave, LDS operations complete in order: no barrier between these writes and the reads below
+        u16 *obase = p.out + (int64_t)(s_begin + q0) * ((int64_t)p.hq * CRAG_HEAD_DIM) + (int64_t)head * CRAG_HEAD_DIM;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (lane >> 4) + 4 * it, chunk = lane & 15;
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ot + row * ATT_KROW + 8 * chunk);
+            if (q0 + row < len)
+                *reinterpret_cast<bf16x8 *>(obase + (int64_t)row * ((int64_t)p.hq * CRAG_HEAD_DIM) + 8 * chunk) = v;
+        }
     }
 }
 
@@ -419,8 +435,12 @@ template <int GROUP>
 __global__ __launch_bounds__(64 * GROUP) __attribute__((amdgpu_waves_per_eu(2, 8)))
 void attention_pair_kernel(AttnParams p) {
     static_assert(GROUP >= 4, "staging is sized for at least 256 threads");
-    __shared__ __attribute__((aligned(16))) u16 s_k[2][64 * ATT_KROW];
-    __shared__ __attribute__((aligned(16))) u16 s_v[2][CRAG_HEAD_DIM * ATT_VROW2];
+    // one pool: K buffers, then V^T buffers; the epilogue reuses its start for the per-wave output tiles
+    constexpr int K_BUF = 64 * ATT_KROW, V_BUF = CRAG_HEAD_DIM * ATT_VROW2;
+    static_assert(GROUP * 32 * ATT_KROW <= 2 * (K_BUF + V_BUF), "output tiles must fit the staging pool");
+    __shared__ __attribute__((aligned(16))) u16 s_pool[2 * (K_BUF + V_BUF)];
+    u16(*s_k)[K_BUF] = reinterpret_cast<u16(*)[K_BUF]>(s_pool);
+    u16(*s_v)[V_BUF] = reinterpret_cast<u16(*)[V_BUF]>(s_pool + 2 * K_BUF);
     constexpr int nthr = 64 * GROUP;
     constexpr int per = 1024 / nthr;  // 16-byte chunks of K and of V^T per thread and pair
     const int tid = threadIdx.x;
@@ -594,10 +614,13 @@ void attention_pair_kernel(AttnParams p) {
     if (last_half) pair(n_pairs - 1, std::true_type{}, std::true_type{});
     else pair(n_pairs - 1, std::false_type{}, std::true_type{});
 
-    if (q0 + c < len) {
+    // O[q0 + c][32 dt + (i&3) + 8 (i>>2) + 4h] = oacc[dt][i] / l.  Stored straight from these registers a wave
+    // instruction would write 16 bytes into each of 32 rows (partial lines: 40 % of the kernel's time at
+    // 256-token chunks); instead the wave transposes its 32 x 128 tile through LDS (the K staging buffer is free
+    // after the last barrier) and writes whole 256-byte rows, 16 bytes per lane.
+    {
+        u16 *ot = s_pool + wave * (32 * ATT_KROW);
         const float inv = 1.f / l;
-        u16 *op = p.out + (int64_t)(s_begin + q0 + c) * ((int64_t)p.hq * CRAG_HEAD_DIM) +
-                  (int64_t)head * CRAG_HEAD_DIM + 4 * h;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -605,8 +628,17 @@ void attention_pair_kernel(AttnParams p) {
                 uint2 w;
                 w.x = (uint32_t)f2bf(oacc[dt][4 * g4] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 1] * inv) << 16);
                 w.y = (uint32_t)f2bf(oacc[dt][4 * g4 + 2] * inv) | ((uint32_t)f2bf(oacc[dt][4 * g4 + 3] * inv) << 16);
-                *reinterpret_cast<uint2 *>(op + 32 * dt + 8 * g4) = w;
+                *reinterpret_cast<uint2 *>(ot + c * ATT_KROW + 32 * dt + 8 * g4 + 4 * h) = w;
             }
+        // same wave, LDS operations complete in order: no barrier between these writes and the reads below
+        u16 *obase = p.out + (int64_t)(s_begin + q0) * ((int64_t)p.hq * CRAG_HEAD_DIM) + (int64_t)head * CRAG_HEAD_DIM;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = (lane >> 4) + 4 * it, chunk = lane & 15;
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(ot + row * ATT_KROW + 8 * chunk);
+            if (q0 + row < len)
+                *reinterpret_cast<bf16x8 *>(obase + (int64_t)row * ((int64_t)p.hq * CRAG_HEAD_DIM) + 8 * chunk) = v;
+        }
     }
 }
 
