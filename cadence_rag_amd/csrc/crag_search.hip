@@ -613,11 +613,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
             }
             a[s] = v;
         }
-        double ss = 0.0;
+        // four independent fp64 chains (one per component): a single dependent chain of 64 fp64 FMAs per
+        // wave costs several microseconds of every launch
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) ss += (double)a[s][cc] * (double)a[s][cc];
+            for (int cc = 0; cc < 4; ++cc) s4[cc] += (double)a[s][cc] * (double)a[s][cc];
+        double ss = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         ss += __shfl_xor(ss, 32);
         if (c.h == 0) red[w][j] = ss;  // read after the first barrier of the tile loop
     }
@@ -985,7 +988,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
         const int qi = ((int)blockIdx.y * NQB + qb) * 32 + j;
         const bool have = qi < p.nq;
         const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
-        double ss = 0.0;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int col = w * KSLICE + 8 * s + 4 * c.h;
@@ -1000,9 +1002,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 }
             }
             a[qb][s] = v;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) ss += (double)v[cc] * (double)v[cc];
         }
+        // after all loads are issued: four independent fp64 chains (one per component) instead of one
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) s4[cc] += (double)a[qb][s][cc] * (double)a[qb][s][cc];
+        double ss = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         ss += __shfl_xor(ss, 32);
         if (c.h == 0) L.red[w][qb][j] = ss;  // combined after the first barrier of the tile loop
 #pragma unroll
