@@ -95,7 +95,11 @@ struct crag_index {
         hipStream_t stream = nullptr;
         bool in_use = false;
         DevBuf partial, gbound;
+        hipEvent_t done = nullptr;   // recorded after every search that used this workspace
+        uint64_t last_use = 0;
     } ws[MAX_WS];
+    uint64_t use_clock = 0;
+    bool track_done = false;  // set once a workspace had to be taken over from another stream
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
     int pass_parity = 0;  // alternate scan direction between searches (Infinity Cache reuse)
@@ -149,7 +153,22 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                 ws = &w;
                 break;
             }
-    if (!ws) return fail(CRAG_EINVAL, "more than %d distinct streams used with one index", crag_index::MAX_WS);
+    if (!ws) {
+        // every workspace belongs to some other stream: take the least recently used one and make this
+        // stream wait for the last search that used it (its owner may even be gone by now)
+        for (auto &w : ix->ws)
+            if (!ws || w.last_use < ws->last_use) ws = &w;
+        if (ws->done) {
+            HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
+        } else {
+            // first take-over: until now no completion events were recorded (the common case of <= 4
+            // streams pays nothing for them); drain the device once and record from here on
+            HIP_TRY(hipDeviceSynchronize());
+            ix->track_done = true;
+        }
+        ws->stream = st;
+    }
+    ws->last_use = ++ix->use_clock;
     if ((rc = ws->partial.ensure((size_t)q_blocks * G * 32 * (size_t)k * sizeof(uint2)))) return rc;
     {
         const size_t gb_bytes = (size_t)q_blocks * 32 * crag::GB_CELLS * sizeof(uint32_t);
@@ -214,6 +233,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     mp.G = G;
     HIP_TRY(crag::launch_merge_partials(mp, nq, st));
     if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
+    if (ix->track_done) {
+        if (!ws->done) HIP_TRY(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ws->done, st));
+    }
     return CRAG_OK;
 }
 
@@ -313,6 +336,7 @@ int crag_index_destroy(crag_index *ix) {
     for (auto &w : ix->ws) {
         w.partial.release();
         w.gbound.release();
+        if (w.done) (void)hipEventDestroy(w.done);
     }
     ix->stage_q.release();
     ix->stage_rows.release();

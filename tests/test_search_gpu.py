@@ -627,3 +627,55 @@ def test_property_random_shapes_masks_and_k(gpu):
         _check(corpus, q, k, mask=mask)
 
     run()
+
+
+def test_concurrent_host_threads_and_streams(gpu):
+    """crag_index_search is documented thread-safe (FastAPI serves sync endpoints from a thread pool) and
+    crag_index_search_async may be used from up to four streams at once: answers must not depend on it."""
+    import threading
+    import torch
+    rng = np.random.default_rng(404)
+    n = 30000
+    corpus = unit_rows(rng, n)
+    qs = [rng.standard_normal((int(nq), 1024)).astype(np.float32) for nq in (1, 7, 33, 64, 20, 3)]
+    ks = [10, 50, 10, 10, 100, 128]
+    with DenseIndex(1024, capacity=n) as ix:
+        ix.add(corpus)
+        want = [ix.search(q, k) for q, k in zip(qs, ks)]
+        errors = []
+
+        def worker(tid):
+            try:
+                for rep in range(15):
+                    i = (tid + rep) % len(qs)
+                    got = ix.search(qs[i], ks[i])
+                    for a, b in zip(got, want[i]):
+                        assert np.array_equal(a, b, equal_nan=True)
+            except Exception as exc:  # noqa: BLE001
+                errors.append(repr(exc))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors[:2]
+        # four streams, device buffers, launched back to back without synchronising in between
+        dev = torch.device("cuda", 0)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        outs = []
+        for rep in range(3):
+            for si, st in enumerate(streams):
+                i = (si + rep) % len(qs)
+                dq = torch.from_numpy(qs[i]).to(dev)
+                o = (torch.empty(len(qs[i]), ks[i], dtype=torch.int64, device=dev),
+                     torch.empty(len(qs[i]), ks[i], dtype=torch.float32, device=dev),
+                     torch.empty(len(qs[i]), dtype=torch.int32, device=dev))
+                torch.cuda.current_stream().synchronize()  # the H2D copy above ran on the default stream
+                ix.search_async(dq, ks[i], *o, stream=st.cuda_stream)
+                outs.append((i, o, dq))
+        torch.cuda.synchronize()
+        for i, o, _ in outs:
+            assert np.array_equal(o[0].cpu().numpy(), want[i][0])
+            assert np.array_equal(o[1].cpu().numpy(), want[i][1], equal_nan=True)
+            assert np.array_equal(o[2].cpu().numpy(), want[i][2])
