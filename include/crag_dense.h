@@ -55,7 +55,10 @@ int crag_index_destroy(crag_index *ix);
 /* Append n rows ([n, dim] row-major fp32; host OR device pointer, detected) with their
  * 64-bit ids (NULL => consecutive ids continuing from the current size).  Rows with a zero
  * or non-finite norm are stored but never returned (pgvector gives them a NaN distance).
- * Replaces: _update_embeddings' per-row UPDATE (embedding_pipeline.py:157-168). */
+ * Replaces: _update_embeddings' per-row UPDATE (embedding_pipeline.py:157-168).
+ * Appending is safe while searches enqueued earlier with crag_index_search_async are still running (they
+ * never read past the size they were launched with); crag_index_update rewrites rows in place and must
+ * not overlap in time with searches in flight on other streams. */
 int crag_index_add(crag_index *ix, const float *rows, const int64_t *ids, int64_t n);
 
 /* Overwrite the vectors of rows [pos, pos+n) (positions, not ids) — re-embed in place. */
