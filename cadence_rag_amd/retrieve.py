@@ -415,187 +415,204 @@ def set_backend(backend: Optional[RetrieveBackend]) -> None:
     _backend = backend
 
 
+@dataclass(frozen=True)
+class _Side:
+    """One of the two evidence tables as /retrieve sees it: which lanes feed it, how one of its rows becomes
+    an evidence item and which caps apply.  The response of /root/reference/app/retrieve.py:392-688 is a
+    function of these two records and the request; tests/golden/reference_retrieve_evidence.json pins it."""
+    table: str          # backend table name, also the key inside notes/debug dictionaries
+    out: str            # response list ("artifacts" / "quotes") and debug.lanes key
+    debug_key: str
+    id_field: str
+    tag: str            # ids_only prefix
+    rank: int           # ids_only tie order: lower first
+    letter: str         # evidence_id prefix
+    body: str           # column the snippet is cut from
+    carry: Tuple[str, ...]   # columns copied into the item, in response order
+    bm25_topk: int
+    dense_topk: int
+    list_cap: Optional[int]  # at most this many items of this kind
+    per_call: Optional[int]  # at most this many per call_id
+
+
+_SIDES = (
+    _Side("artifact_chunks", "artifacts", "artifacts", "artifact_chunk_id", "artifact_chunk", 0, "A", "content",
+          ("artifact_id", "artifact_chunk_id", "kind"), DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
+          DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK, DEFAULT_MAX_ARTIFACTS, None),
+    _Side("chunks", "quotes", "chunks", "chunk_id", "chunk", 1, "Q", "text",
+          ("chunk_id", "speaker", "start_ts_ms", "end_ts_ms"), DEFAULT_CHUNK_BM25_TOPK,
+          DEFAULT_DENSE_CHUNK_TOPK, None, DEFAULT_MAX_QUOTES_PER_CALL),
+)
+_BY_TABLE = {s.table: s for s in _SIDES}
+# the backend is queried chunks first (the reference's statement order; the replay backend records it)
+_QUERY_ORDER = (_BY_TABLE["chunks"], _BY_TABLE["artifact_chunks"])
+
+
+class _Purse:
+    """The request budget while the evidence pack is being filled."""
+
+    def __init__(self, budget: Budget) -> None:
+        self.items = budget.max_evidence_items
+        self.chars = budget.max_total_chars
+
+    @property
+    def spent(self) -> bool:
+        return self.items <= 0 or self.chars <= 0
+
+
+def _pack(ranked, side: _Side, purse: _Purse, item_cap: Optional[int]) -> List[Dict[str, Any]]:
+    """Ranked rows of one side -> evidence items, best first, until the purse or the side's caps run out.
+    A row over its call's quota is passed over without ending the walk."""
+    out: List[Dict[str, Any]] = []
+    used_by_call: Dict[str, int] = {}
+    for row, lanes, _ in ranked:
+        if purse.spent or (item_cap is not None and len(out) >= item_cap):
+            break
+        call = str(row["call_id"])
+        if side.per_call is not None:
+            if used_by_call.get(call, 0) >= side.per_call:
+                continue
+            used_by_call[call] = used_by_call.get(call, 0) + 1
+        snippet = _clip(row[side.body], min(DEFAULT_SNIPPET_CHARS, purse.chars))
+        purse.chars -= len(snippet)
+        purse.items -= 1
+        item = {"evidence_id": f"{side.letter}-{row[side.id_field]}", "call_id": call}
+        item.update((col, row[col]) for col in side.carry)
+        item["snippet"] = snippet
+        item["why_relevant"] = " + ".join(sorted(lanes))
+        out.append(item)
+    return out
+
+
+class _DenseState:
+    """What the dense lane contributed to one request (all of it is echoed in notes / debug)."""
+
+    def __init__(self) -> None:
+        self.on = False
+        self.model_id: Optional[str] = None
+        self.error: Optional[str] = None
+        self.literal: Optional[str] = None
+        self.mode: Dict[str, Optional[str]] = {s.table: None for s in _QUERY_ORDER}
+        self.candidates: Dict[str, int] = {s.table: 0 for s in _QUERY_ORDER}
+
+    def embed(self, query: str) -> None:
+        from . import embeddings as _emb
+        self.on = _emb.embeddings_enabled()
+        if not self.on:
+            return
+        try:  # fail-open: a broken encoder turns the lane off for this request and is reported
+            res = _emb.embed_texts([query])
+        except _emb.EmbeddingClientError as exc:
+            self.on, self.error = False, str(exc)
+            return
+        self.model_id, self.literal = res.model, _vector_literal(res.vectors[0])
+
+    @property
+    def planner(self) -> str:
+        if not self.on:
+            return "lexical_only"
+        return "ann" if "ann" in self.mode.values() else "exact"
+
+    def topk(self, side: _Side) -> int:
+        return side.dense_topk if self.on else 0
+
+
+def _gather_lanes(be: "RetrieveBackend", query: str, tokens: List[str], filters, dense: _DenseState
+                  ) -> Dict[str, Dict[str, Sequence[Dict[str, Any]]]]:
+    """table -> {lane name -> rows}, lanes in fusion order (bm25, tech_tokens, dense)."""
+    call_ids = be.resolve_call_ids(filters)
+    fetch = {"chunks": (be.fetch_chunks_bm25, be.fetch_chunks_tech, be.fetch_chunks_dense),
+             "artifact_chunks": (be.fetch_artifacts_bm25, be.fetch_artifacts_tech, be.fetch_artifacts_dense)}
+    lanes: Dict[str, Dict[str, Sequence[Dict[str, Any]]]] = {s.table: {} for s in _QUERY_ORDER}
+    for s in _QUERY_ORDER:
+        lanes[s.table]["bm25"] = fetch[s.table][0](query, filters, call_ids, s.bm25_topk)
+    for s in _QUERY_ORDER:
+        lanes[s.table]["tech_tokens"] = fetch[s.table][1](tokens, filters, call_ids, DEFAULT_TECH_TOPK)
+    if dense.on and dense.literal is not None:
+        for s in _QUERY_ORDER:
+            dense.candidates[s.table] = be.estimate_dense_candidates(s.table, filters, call_ids)
+        for s in _QUERY_ORDER:
+            dense.mode[s.table] = _choose_dense_mode(dense.candidates[s.table], filters, call_ids)
+    if dense.on:
+        for s in _QUERY_ORDER:
+            lanes[s.table]["dense"] = (fetch[s.table][2](dense.literal, filters, call_ids, dense.mode[s.table],
+                                                         s.dense_topk) if dense.literal is not None else [])
+    return lanes
+
+
+def _debug_section(lanes, dense: _DenseState) -> Dict[str, Any]:
+    chunks, artifacts = _BY_TABLE["chunks"], _BY_TABLE["artifact_chunks"]
+    return {
+        "lanes": {s.debug_key: {name: _build_debug_lane(rows, s.id_field) for name, rows in lanes[s.table].items()}
+                  for s in _QUERY_ORDER},
+        "limits": {"bm25_chunk_topk": chunks.bm25_topk, "bm25_artifact_chunk_topk": artifacts.bm25_topk,
+                   "tech_token_topk": DEFAULT_TECH_TOPK, "dense_chunk_topk": dense.topk(chunks),
+                   "dense_artifact_chunk_topk": dense.topk(artifacts)},
+        "dense": {"enabled": dense.on, "model_id": dense.model_id, "error": dense.error,
+                  "modes": dict(dense.mode), "candidate_rows": dict(dense.candidates)},
+    }
+
+
+def _retrieval_notes(tokens: List[str], dense: _DenseState) -> Dict[str, Any]:
+    chunks, artifacts = _BY_TABLE["chunks"], _BY_TABLE["artifact_chunks"]
+    return {
+        "planner": dense.planner,
+        "dense_topk": max(dense.topk(chunks), dense.topk(artifacts)),
+        "lex_topk": chunks.bm25_topk,
+        "artifact_chunk_lex_topk": artifacts.bm25_topk,
+        "reranked_from": None,
+        "bm25_chunk_topk": chunks.bm25_topk,
+        "bm25_artifact_chunk_topk": artifacts.bm25_topk,
+        "tech_token_topk": DEFAULT_TECH_TOPK,
+        "tech_tokens": tokens,
+        "lanes": {"bm25": True, "tech_tokens": True, "dense": dense.on},
+        "dense_model_id": dense.model_id,
+        "dense_error": dense.error,
+        "dense_modes": dict(dense.mode),
+        "dense_candidate_rows": dict(dense.candidates),
+        "hnsw_ef_search": settings.embeddings_hnsw_ef_search if dense.on else None,
+    }
+
+
 def retrieve_evidence(payload: RetrieveRequest, backend: Optional[RetrieveBackend] = None) -> Dict[str, Any]:
-    """Drop-in for retrieve_evidence (retrieve.py:392-688): same response dict, key for key."""
+    """The /retrieve entry point (S9; reference: /root/reference/app/retrieve.py:392-688): lexical lanes and
+    the dense lane per table -> RRF -> either the fused id list or a budgeted evidence pack.  Built from the
+    response contract (ten reference-captured scenarios), table-driven over `_SIDES`."""
     from uuid import uuid4
 
-    from . import embeddings as _emb
     from .tech_tokens import extract_tech_tokens
 
     be = backend if backend is not None else _backend
     if be is None:
         raise RuntimeError("retrieve_evidence: no backend registered (set_backend)")
-    query_id = str(uuid4())
-    query = payload.query.strip()
+    head: Dict[str, Any] = {"query_id": str(uuid4())}
+    ids_only = payload.return_style == "ids_only"
     budget = payload.budget or Budget()
-    return_style = payload.return_style
-
+    query = payload.query.strip()
     if not query:
-        if return_style == "ids_only":
-            return {"query_id": query_id, "retrieved_ids": []}
-        return {"query_id": query_id, "intent": payload.intent, "budget": budget.model_dump(),
-                "artifacts": [], "quotes": [], "notes": {"error": "empty query"}}
+        if ids_only:
+            return {**head, "retrieved_ids": []}
+        return {**head, "intent": payload.intent, "budget": budget.model_dump(),
+                **{s.out: [] for s in _SIDES}, "notes": {"error": "empty query"}}
 
-    filters = payload.filters
-    tech_tokens = extract_tech_tokens(query)
-    dense_enabled = _emb.embeddings_enabled()
-    dense_error: Optional[str] = None
-    dense_model_id: Optional[str] = None
-    query_embedding: Optional[str] = None
-    if dense_enabled:
-        try:
-            embedded = _emb.embed_texts([query])
-            dense_model_id = embedded.model
-            query_embedding = _vector_literal(embedded.vectors[0])
-        except _emb.EmbeddingClientError as exc:
-            dense_enabled = False
-            dense_error = str(exc)
+    tokens = extract_tech_tokens(query)
+    dense = _DenseState()
+    dense.embed(query)
+    lanes = _gather_lanes(be, query, tokens, payload.filters, dense)
+    fused = {s.table: _rrf_merge(lanes[s.table], s.id_field) for s in _SIDES}
 
-    dense_chunks: List[Dict[str, Any]] = []
-    dense_artifacts: List[Dict[str, Any]] = []
-    chunk_dense_mode: Optional[str] = None
-    artifact_dense_mode: Optional[str] = None
-    chunk_dense_candidates = 0
-    artifact_dense_candidates = 0
-
-    call_ids = be.resolve_call_ids(filters)
-    bm25_chunks = be.fetch_chunks_bm25(query, filters, call_ids, DEFAULT_CHUNK_BM25_TOPK)
-    bm25_artifacts = be.fetch_artifacts_bm25(query, filters, call_ids, DEFAULT_ARTIFACT_CHUNK_BM25_TOPK)
-    tech_chunks = be.fetch_chunks_tech(tech_tokens, filters, call_ids, DEFAULT_TECH_TOPK)
-    tech_artifacts = be.fetch_artifacts_tech(tech_tokens, filters, call_ids, DEFAULT_TECH_TOPK)
-    if dense_enabled and query_embedding is not None:
-        chunk_dense_candidates = be.estimate_dense_candidates("chunks", filters, call_ids)
-        artifact_dense_candidates = be.estimate_dense_candidates("artifact_chunks", filters, call_ids)
-        chunk_dense_mode = _choose_dense_mode(chunk_dense_candidates, filters, call_ids)
-        artifact_dense_mode = _choose_dense_mode(artifact_dense_candidates, filters, call_ids)
-        dense_chunks = be.fetch_chunks_dense(query_embedding, filters, call_ids, chunk_dense_mode,
-                                             DEFAULT_DENSE_CHUNK_TOPK)
-        dense_artifacts = be.fetch_artifacts_dense(query_embedding, filters, call_ids, artifact_dense_mode,
-                                                   DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK)
-
-    debug_payload = None
+    if ids_only:
+        flat = [(-score, s.rank, row[s.id_field], s.tag) for s in _SIDES for row, _, score in fused[s.table]]
+        flat.sort(key=lambda t: t[:3])
+        response = {**head, "retrieved_ids": [f"{tag}:{rid}" for _, _, rid, tag in flat]}
+    else:
+        purse = _Purse(budget)
+        packed = {}
+        for s in _SIDES:  # artifacts are packed first and share the purse with the quotes
+            cap = None if s.list_cap is None else min(s.list_cap, budget.max_evidence_items)
+            packed[s.out] = _pack(fused[s.table], s, purse, cap)
+        response = {**head, "intent": payload.intent, "budget": budget.model_dump(), **packed,
+                    "notes": {"retrieval": _retrieval_notes(tokens, dense)}}
     if payload.debug:
-        chunk_lanes_debug = {"bm25": _build_debug_lane(bm25_chunks, "chunk_id"),
-                             "tech_tokens": _build_debug_lane(tech_chunks, "chunk_id")}
-        artifact_lanes_debug = {"bm25": _build_debug_lane(bm25_artifacts, "artifact_chunk_id"),
-                                "tech_tokens": _build_debug_lane(tech_artifacts, "artifact_chunk_id")}
-        if dense_enabled:
-            chunk_lanes_debug["dense"] = _build_debug_lane(dense_chunks, "chunk_id")
-            artifact_lanes_debug["dense"] = _build_debug_lane(dense_artifacts, "artifact_chunk_id")
-        debug_payload = {
-            "lanes": {"chunks": chunk_lanes_debug, "artifacts": artifact_lanes_debug},
-            "limits": {
-                "bm25_chunk_topk": DEFAULT_CHUNK_BM25_TOPK,
-                "bm25_artifact_chunk_topk": DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
-                "tech_token_topk": DEFAULT_TECH_TOPK,
-                "dense_chunk_topk": DEFAULT_DENSE_CHUNK_TOPK if dense_enabled else 0,
-                "dense_artifact_chunk_topk": DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK if dense_enabled else 0,
-            },
-            "dense": {
-                "enabled": dense_enabled,
-                "model_id": dense_model_id,
-                "error": dense_error,
-                "modes": {"chunks": chunk_dense_mode, "artifact_chunks": artifact_dense_mode},
-                "candidate_rows": {"chunks": chunk_dense_candidates, "artifact_chunks": artifact_dense_candidates},
-            },
-        }
-
-    chunk_lanes: Dict[str, Sequence[Dict[str, Any]]] = {"bm25": bm25_chunks, "tech_tokens": tech_chunks}
-    artifact_lanes: Dict[str, Sequence[Dict[str, Any]]] = {"bm25": bm25_artifacts, "tech_tokens": tech_artifacts}
-    if dense_enabled:
-        chunk_lanes["dense"] = dense_chunks
-        artifact_lanes["dense"] = dense_artifacts
-    chunk_ranked = _rrf_merge(chunk_lanes, "chunk_id")
-    artifact_ranked = _rrf_merge(artifact_lanes, "artifact_chunk_id")
-
-    if return_style == "ids_only":
-        combined = [("artifact_chunk", row["artifact_chunk_id"], score) for row, _l, score in artifact_ranked]
-        combined += [("chunk", row["chunk_id"], score) for row, _l, score in chunk_ranked]
-        kind_order = {"artifact_chunk": 0, "chunk": 1}
-        combined.sort(key=lambda item: (-item[2], kind_order[item[0]], item[1]))
-        response: Dict[str, Any] = {"query_id": query_id,
-                                    "retrieved_ids": [f"{kind}:{item_id}" for kind, item_id, _ in combined]}
-        if debug_payload is not None:
-            response["debug"] = debug_payload
-        return response
-
-    max_items = budget.max_evidence_items
-    remaining_chars = budget.max_total_chars
-    artifacts_out: List[Dict[str, Any]] = []
-    quotes_out: List[Dict[str, Any]] = []
-    max_artifacts = min(DEFAULT_MAX_ARTIFACTS, max_items)
-    evidence_count = 0
-    for row, lanes, _score in artifact_ranked:
-        if evidence_count >= max_items or len(artifacts_out) >= max_artifacts:
-            break
-        if remaining_chars <= 0:
-            break
-        snippet = _clip(row["content"], min(DEFAULT_SNIPPET_CHARS, remaining_chars))
-        remaining_chars -= len(snippet)
-        artifacts_out.append({
-            "evidence_id": f"A-{row['artifact_chunk_id']}",
-            "call_id": str(row["call_id"]),
-            "artifact_id": row["artifact_id"],
-            "artifact_chunk_id": row["artifact_chunk_id"],
-            "kind": row["kind"],
-            "snippet": snippet,
-            "why_relevant": " + ".join(sorted(lanes)),
-        })
-        evidence_count += 1
-
-    quotes_per_call: Dict[str, int] = {}
-    for row, lanes, _score in chunk_ranked:
-        if evidence_count >= max_items:
-            break
-        if remaining_chars <= 0:
-            break
-        call_id = str(row["call_id"])
-        if quotes_per_call.get(call_id, 0) >= DEFAULT_MAX_QUOTES_PER_CALL:
-            continue
-        snippet = _clip(row["text"], min(DEFAULT_SNIPPET_CHARS, remaining_chars))
-        remaining_chars -= len(snippet)
-        quotes_out.append({
-            "evidence_id": f"Q-{row['chunk_id']}",
-            "call_id": call_id,
-            "chunk_id": row["chunk_id"],
-            "speaker": row["speaker"],
-            "start_ts_ms": row["start_ts_ms"],
-            "end_ts_ms": row["end_ts_ms"],
-            "snippet": snippet,
-            "why_relevant": " + ".join(sorted(lanes)),
-        })
-        quotes_per_call[call_id] = quotes_per_call.get(call_id, 0) + 1
-        evidence_count += 1
-
-    planner = ("lexical_only" if not dense_enabled
-               else ("ann" if (chunk_dense_mode == "ann" or artifact_dense_mode == "ann") else "exact"))
-    response = {
-        "query_id": query_id,
-        "intent": payload.intent,
-        "budget": budget.model_dump(),
-        "artifacts": artifacts_out,
-        "quotes": quotes_out,
-        "notes": {
-            "retrieval": {
-                "planner": planner,
-                "dense_topk": max(DEFAULT_DENSE_CHUNK_TOPK, DEFAULT_DENSE_ARTIFACT_CHUNK_TOPK) if dense_enabled else 0,
-                "lex_topk": DEFAULT_CHUNK_BM25_TOPK,
-                "artifact_chunk_lex_topk": DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
-                "reranked_from": None,
-                "bm25_chunk_topk": DEFAULT_CHUNK_BM25_TOPK,
-                "bm25_artifact_chunk_topk": DEFAULT_ARTIFACT_CHUNK_BM25_TOPK,
-                "tech_token_topk": DEFAULT_TECH_TOPK,
-                "tech_tokens": tech_tokens,
-                "lanes": {"bm25": True, "tech_tokens": True, "dense": dense_enabled},
-                "dense_model_id": dense_model_id,
-                "dense_error": dense_error,
-                "dense_modes": {"chunks": chunk_dense_mode, "artifact_chunks": artifact_dense_mode},
-                "dense_candidate_rows": {"chunks": chunk_dense_candidates,
-                                         "artifact_chunks": artifact_dense_candidates},
-                "hnsw_ef_search": settings.embeddings_hnsw_ef_search if dense_enabled else None,
-            }
-        },
-    }
-    if debug_payload is not None:
-        response["debug"] = debug_payload
+        response["debug"] = _debug_section(lanes, dense)
     return response
