@@ -95,11 +95,14 @@ struct crag_index {
         hipStream_t stream = nullptr;
         bool in_use = false;
         DevBuf partial, gbound;
-        hipEvent_t done = nullptr;   // recorded after every search that used this workspace
+        hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
         uint64_t last_use = 0;
     } ws[MAX_WS];
     uint64_t use_clock = 0;
-    bool track_done = false;  // set once a workspace had to be taken over from another stream
+    int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
+    // developer switches, read from the environment once, when the index is created
+    bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false;
+    const char *last_scan_kernel = "";  // name of the scan kernel the most recent search launched
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
     int pass_parity = 0;  // alternate scan direction between searches (Infinity Cache reuse)
@@ -138,7 +141,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     if (nq <= 0) return CRAG_OK;
     int q_blocks = (nq + 31) / 32;
     // more than 32 queries and k <= 32: the 64-queries-per-pass kernel (two query blocks per pass)
-    const bool wide = (nq > 32) && !getenv("CRAG_NO_WIDE");
+    const bool wide = (nq > 32) && !ix->env_no_wide;
     if (wide) q_blocks = ((nq + 63) / 64) * 2;
     const int G = scan_groups(ix);
     int rc;
@@ -158,14 +161,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         // stream wait for the last search that used it (its owner may even be gone by now)
         for (auto &w : ix->ws)
             if (!ws || w.last_use < ws->last_use) ws = &w;
-        if (ws->done) {
-            HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
-        } else {
-            // first take-over: until now no completion events were recorded (the common case of <= 4
-            // streams pays nothing for them); drain the device once and record from here on
-            HIP_TRY(hipDeviceSynchronize());
-            ix->track_done = true;
-        }
+        HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
         ws->stream = st;
     }
     ws->last_use = ++ix->use_clock;
@@ -203,8 +199,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     sp.pub_rank = (k + sp.nb - 1) / sp.nb - 1;
     sp.reverse = ix->pass_parity;
     ix->pass_parity ^= 1;
-    if (getenv("CRAG_NO_REVERSE")) sp.reverse = 0;
-    sp.unpipelined = getenv("CRAG_UNPIPELINED") ? 1 : 0;
+    if (ix->env_no_reverse) sp.reverse = 0;
+    sp.unpipelined = ix->env_unpipelined ? 1 : 0;
 
     EvTriple *ev = nullptr;
     if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == 0) {
@@ -218,7 +214,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         ev = &ix->ev_pool[ix->ev_used++];
         HIP_TRY(hipEventRecord(ev->e0, st));
     }
-    HIP_TRY(crag::launch_scan(sp, q_blocks, st));
+    HIP_TRY(crag::launch_scan(sp, q_blocks, st, &ix->last_scan_kernel));
     if (ev) HIP_TRY(hipEventRecord(ev->e1, st));
 
     crag::MergeParams mp;
@@ -233,10 +229,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     mp.G = G;
     HIP_TRY(crag::launch_merge_partials(mp, nq, st));
     if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
-    if (ix->track_done) {
-        if (!ws->done) HIP_TRY(hipEventCreateWithFlags(&ws->done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(ws->done, st));
-    }
+    HIP_TRY(hipEventRecord(ws->done, st));  // what a stream that later takes this workspace over waits for
     return CRAG_OK;
 }
 
@@ -317,6 +310,15 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
         crag_index_destroy(ix);
         return rc;
     }
+    for (auto &w : ix->ws)
+        if ((e = hipEventCreateWithFlags(&w.done, hipEventDisableTiming)) != hipSuccess) {
+            int rc = fail(CRAG_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+            crag_index_destroy(ix);
+            return rc;
+        }
+    ix->env_no_wide = getenv("CRAG_NO_WIDE") != nullptr;
+    ix->env_no_reverse = getenv("CRAG_NO_REVERSE") != nullptr;
+    ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     *out = ix;
     return CRAG_OK;
 }
@@ -384,6 +386,35 @@ int crag_index_add(crag_index *ix, const float *rows, const int64_t *ids, int64_
     if (ix->size + n >= (int64_t)0xfffffff0ll) return fail(CRAG_ENOMEM, "more than 2^32 rows per index");
     DeviceGuard guard(ix->device);
     const int64_t pos = ix->size;
+    // ids must grow with the row position: that is what makes "equal scores by ascending position" inside
+    // the scan the same order as "equal scores by ascending id"  and as the cross-shard merge
+    int64_t new_last;
+    if (!ids) {
+        if (pos <= ix->last_id)
+            return fail(CRAG_EINVAL, "implicit ids would start at %lld, not above the largest stored id %lld",
+                        (long long)pos, (long long)ix->last_id);
+        new_last = pos + n - 1;
+    } else if (is_device_ptr(ids)) {
+        int rc0 = ix->scratch.ensure(sizeof(unsigned long long));
+        if (rc0) return rc0;
+        HIP_TRY(hipMemsetAsync(ix->scratch.p, 0, sizeof(unsigned long long), 0));
+        HIP_TRY(crag::launch_check_ids(ids, n, ix->last_id, (unsigned long long *)ix->scratch.p, 0));
+        unsigned long long bad = 0;
+        HIP_TRY(hipMemcpy(&bad, ix->scratch.p, sizeof(bad), hipMemcpyDeviceToHost));
+        if (bad)
+            return fail(CRAG_EINVAL, "ids must be strictly ascending and above the largest stored id %lld "
+                        "(%llu of %lld are not)", (long long)ix->last_id, bad, (long long)n);
+        HIP_TRY(hipMemcpy(&new_last, ids + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
+    } else {
+        int64_t prev = ix->last_id;
+        for (int64_t i = 0; i < n; ++i) {
+            if (ids[i] <= prev)
+                return fail(CRAG_EINVAL, "ids must be strictly ascending and above the largest stored id: "
+                            "ids[%lld] = %lld follows %lld", (long long)i, (long long)ids[i], (long long)prev);
+            prev = ids[i];
+        }
+        new_last = prev;
+    }
     int rc = store_rows_locked(ix, pos, rows, n);
     if (rc) return rc;
     if (ids) {
@@ -394,6 +425,7 @@ int crag_index_add(crag_index *ix, const float *rows, const int64_t *ids, int64_
         HIP_TRY(hipStreamSynchronize(0));
     }
     ix->size = pos + n;
+    ix->last_id = new_last;
     return CRAG_OK;
 }
 
@@ -629,6 +661,8 @@ int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms
     ix->ev_used = 0;
     return CRAG_OK;
 }
+
+const char *crag_index_last_scan_kernel(const crag_index *ix) { return ix ? ix->last_scan_kernel : ""; }
 
 int crag_index_scan_geometry(const crag_index *ix, int nq, int *workgroups, int *threads,
                              int *query_blocks, int64_t *algorithmic_bytes_per_launch) {

@@ -59,7 +59,8 @@ struct XMergeParams {
     int k;
 };
 
-hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st);
+// kernel_name (nullable) receives the name of the kernel that was launched (a string literal)
+hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st, const char **kernel_name);
 hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st);
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
@@ -68,6 +69,8 @@ hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n
                             hipStream_t st);
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,
                                  unsigned long long *out, hipStream_t st);
+hipError_t launch_check_ids(const int64_t *ids, int64_t n, int64_t prev, unsigned long long *out_bad,
+                            hipStream_t st);
 hipError_t launch_fill_ids(int64_t *ids, int64_t pos, int64_t n, int64_t first, hipStream_t st);
 
 }  // namespace crag

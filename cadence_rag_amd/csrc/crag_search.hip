@@ -1529,28 +1529,48 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
     if (i < n) ids[pos + i] = first + i;
 }
 
+// number of positions i in [0, n) whose id is not greater than its predecessor's (ids[-1] = prev)
+__global__ __launch_bounds__(256) void check_ids_kernel(const int64_t *ids, int64_t n, int64_t prev,
+                                                        unsigned long long *out_bad) {
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t before = i ? ids[i - 1] : prev;
+        c += ids[i] <= before ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out_bad, c);
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers (called from crag_api.cpp through crag_kernels.h)
 // ------------------------------------------------------------------------------------------
-hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st) {
+hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st, const char **kernel_name) {
     dim3 grid(p.G, q_blocks), block(SCAN_THREADS);
     const int ks = p.k <= 32 ? 1 : (p.k <= 64 ? 2 : 4);
+    const char *name;
+#define CRAG_LAUNCH(GRID_, ...)                                       \
+    do {                                                              \
+        name = "crag::" #__VA_ARGS__;                                 \
+        hipLaunchKernelGGL((__VA_ARGS__), GRID_, block, 0, st, p);    \
+    } while (0)
     if (p.unpipelined) {  // A/B testing only
-        if (ks == 1) hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, st, p);
-        else if (ks == 2) hipLaunchKernelGGL(scan_kernel<2>, grid, block, 0, st, p);
-        else hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, st, p);
+        if (ks == 1) CRAG_LAUNCH(grid, scan_kernel<1>);
+        else if (ks == 2) CRAG_LAUNCH(grid, scan_kernel<2>);
+        else CRAG_LAUNCH(grid, scan_kernel<4>);
     } else if (p.wide) {  // 64 queries per pass (q_blocks is even): the matrix-pipe-bound kernel
         const dim3 g2(p.G, q_blocks / 2);
-        if (ks == 1) hipLaunchKernelGGL((scan_pipe2_kernel<1, 2>), g2, block, 0, st, p);
-        else if (ks == 2) hipLaunchKernelGGL((scan_pipe2_kernel<2, 2>), g2, block, 0, st, p);
-        else hipLaunchKernelGGL((scan_pipe2_kernel<4, 2>), g2, block, 0, st, p);
+        if (ks == 1) CRAG_LAUNCH(g2, scan_pipe2_kernel<1, 2>);
+        else if (ks == 2) CRAG_LAUNCH(g2, scan_pipe2_kernel<2, 2>);
+        else CRAG_LAUNCH(g2, scan_pipe2_kernel<4, 2>);
     } else if (ks == 1) {
-        hipLaunchKernelGGL(scan_pipe_kernel, grid, block, 0, st, p);
+        CRAG_LAUNCH(grid, scan_pipe_kernel);
     } else if (ks == 2) {
-        hipLaunchKernelGGL((scan_pipe2_kernel<2, 1>), grid, block, 0, st, p);
+        CRAG_LAUNCH(grid, scan_pipe2_kernel<2, 1>);
     } else {
-        hipLaunchKernelGGL((scan_pipe2_kernel<4, 1>), grid, block, 0, st, p);
+        CRAG_LAUNCH(grid, scan_pipe2_kernel<4, 1>);
     }
+#undef CRAG_LAUNCH
+    if (kernel_name) *kernel_name = name;
     return hipGetLastError();
 }
 
@@ -1582,6 +1602,15 @@ hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,
                                  unsigned long long *out, hipStream_t st) {
     hipLaunchKernelGGL(count_eligible_kernel, dim3(1024), dim3(256), 0, st, inv_norm, n, mask, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_check_ids(const int64_t *ids, int64_t n, int64_t prev, unsigned long long *out_bad,
+                            hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(check_ids_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, ids, n,
+                       prev, out_bad);
     return hipGetLastError();
 }
 

@@ -109,6 +109,17 @@ class DenseIndex:
                                                     ids.ctypes.data), "crag_index_get_rows")
         return rows, ids
 
+    def get_rows_into(self, pos: int, n: int, d_rows) -> np.ndarray:
+        """Device-to-device form of get_rows: rows [pos, pos+n) into the float32 CUDA tensor d_rows
+        ([n, dim], contiguous); returns their ids (host)."""
+        if tuple(d_rows.shape) != (n, self.dim) or not d_rows.is_contiguous() or d_rows.dtype != torch.float32:
+            raise ValueError(f"d_rows must be a contiguous float32 [{n}, {self.dim}] tensor")
+        ids = np.empty((n,), dtype=np.int64)
+        if n:
+            _native.check(self._lib.crag_index_get_rows(self._h, int(pos), int(n), d_rows.data_ptr(),
+                                                        ids.ctypes.data), "crag_index_get_rows")
+        return ids
+
     @staticmethod
     def pack_mask(eligible) -> np.ndarray:
         """bool [n] or [nq, n] -> the bit mask the C ABI takes (bit i&7 of byte i>>3), with each
@@ -185,6 +196,11 @@ class DenseIndex:
         _native.check(self._lib.crag_index_profile_read(self._h, ctypes.byref(n), ctypes.byref(scan),
                                                         ctypes.byref(merge)), "profile_read")
         return int(n.value), float(scan.value), float(merge.value)
+
+    def last_scan_kernel(self) -> str:
+        """Name of the scan kernel the most recent search launched (as rocprofv3 prints it)."""
+        name = self._lib.crag_index_last_scan_kernel(self._h)
+        return name.decode() if name else ""
 
     def scan_geometry(self, nq: int) -> dict:
         wg, th, qb = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)

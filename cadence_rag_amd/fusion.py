@@ -13,6 +13,14 @@ from . import _native
 DEFAULT_RRF_K = 60
 
 
+def _on_stream(stream: int, device):
+    """Context in which torch allocates, uploads and frees on the caller's HIP stream, so that every
+    temporary of a call is ordered with the kernels the C ABI enqueues on that same stream (stream 0 =
+    the null stream, which is also torch's default current stream)."""
+    return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device) if stream else
+                             torch.cuda.default_stream(device))
+
+
 def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf_k: int = DEFAULT_RRF_K,
              stream: int = 0) -> Dict[str, torch.Tensor]:
     """lanes: [(ids int64 [nq, width] CUDA, counts int32 [nq] CUDA), ...] in lane order (the
@@ -22,18 +30,20 @@ def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf
     n = len(lanes)
     nq = int(lanes[0][0].shape[0])
     dev = lanes[0][0].device
-    ids_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(t.contiguous().data_ptr()) for t, _ in lanes])
-    cnt_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(c.contiguous().data_ptr()) for _, c in lanes])
-    width = (ctypes.c_int * n)(*[int(t.shape[1]) for t, _ in lanes])
-    out = {
-        "ids": torch.empty(nq, out_k, dtype=torch.int64, device=dev),
-        "scores": torch.empty(nq, out_k, dtype=torch.float64, device=dev),
-        "lanes": torch.empty(nq, out_k, dtype=torch.int32, device=dev),
-        "counts": torch.empty(nq, dtype=torch.int32, device=dev),
-    }
-    _native.check(lib.crag_rrf_fuse(n, ids_arr, cnt_arr, width, nq, int(rrf_k), int(out_k), out["ids"].data_ptr(),
-                                    out["scores"].data_ptr(), out["lanes"].data_ptr(), out["counts"].data_ptr(),
-                                    ctypes.c_void_p(stream)), "crag_rrf_fuse")
+    with _on_stream(stream, dev):
+        keep = [(t.contiguous(), c.contiguous()) for t, c in lanes]
+        ids_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(t.data_ptr()) for t, _ in keep])
+        cnt_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(c.data_ptr()) for _, c in keep])
+        width = (ctypes.c_int * n)(*[int(t.shape[1]) for t, _ in keep])
+        out = {
+            "ids": torch.empty(nq, out_k, dtype=torch.int64, device=dev),
+            "scores": torch.empty(nq, out_k, dtype=torch.float64, device=dev),
+            "lanes": torch.empty(nq, out_k, dtype=torch.int32, device=dev),
+            "counts": torch.empty(nq, dtype=torch.int32, device=dev),
+        }
+        _native.check(lib.crag_rrf_fuse(n, ids_arr, cnt_arr, width, nq, int(rrf_k), int(out_k),
+                                        out["ids"].data_ptr(), out["scores"].data_ptr(), out["lanes"].data_ptr(),
+                                        out["counts"].data_ptr(), ctypes.c_void_p(stream)), "crag_rrf_fuse")
     return out
 
 
@@ -73,32 +83,64 @@ class TechTokenIndex:
         self.row_ptr = torch.from_numpy(row_ptr).to(device)
         self.tokens = torch.from_numpy(toks.view(np.int64)).to(device)
         self.ids = torch.from_numpy(ids).to(device)
-        self._bitmap = None
+        self._bitmaps: dict = {}   # per stream: two streams sharing one index must not share scratch
+        self._rank_of_id = None
 
-    def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0):
-        """query_token_lists: per query the tokens of extract_tech_tokens(query) (at most 64 queries).
-        Returns (ids int64 [nq, k] -1 padded, counts int32 [nq]) CUDA tensors, best (most recent) first."""
-        nq = len(query_token_lists)
+    def _pass(self, token_lists, k: int, row_mask, mask_stride: int, stream: int):
+        """One launch of the lane: at most MAX_QUERY_TOKENS tokens per query."""
+        nq = len(token_lists)
         qt = np.zeros((nq, MAX_QUERY_TOKENS), dtype=np.uint64)
         qn = np.zeros(nq, dtype=np.int32)
-        for i, toks in enumerate(query_token_lists):
-            toks = list(toks)[:MAX_QUERY_TOKENS]
+        for i, toks in enumerate(token_lists):
             qt[i, :len(toks)] = [token_hash(t) for t in toks]
             qn[i] = len(toks)
-        d_qt = torch.from_numpy(qt.view(np.int64)).to(self.device)
-        d_qn = torch.from_numpy(qn).to(self.device)
         words = max((self.n + 63) // 64, 1)
-        if self._bitmap is None or self._bitmap.numel() < nq * words:
-            self._bitmap = torch.empty(nq * words, dtype=torch.int64, device=self.device)
-        out_ids = torch.empty(nq, k, dtype=torch.int64, device=self.device)
-        out_ct = torch.empty(nq, dtype=torch.int32, device=self.device)
-        lib = _native.load()
-        _native.check(lib.crag_tech_lane(self.order.data_ptr(), self.row_ptr.data_ptr(), self.tokens.data_ptr(),
-                                         self.ids.data_ptr(), self.n, d_qt.data_ptr(), d_qn.data_ptr(), nq, int(k),
-                                         None if row_mask is None else row_mask.data_ptr(), int(mask_stride),
-                                         self._bitmap.data_ptr(), out_ids.data_ptr(), out_ct.data_ptr(),
-                                         ctypes.c_void_p(stream)), "crag_tech_lane")
+        with _on_stream(stream, self.device):
+            d_qt = torch.from_numpy(qt.view(np.int64)).to(self.device)
+            d_qn = torch.from_numpy(qn).to(self.device)
+            bitmap = self._bitmaps.get(stream)
+            if bitmap is None or bitmap.numel() < nq * words:
+                bitmap = self._bitmaps[stream] = torch.empty(nq * words, dtype=torch.int64, device=self.device)
+            out_ids = torch.empty(nq, k, dtype=torch.int64, device=self.device)
+            out_ct = torch.empty(nq, dtype=torch.int32, device=self.device)
+            lib = _native.load()
+            _native.check(lib.crag_tech_lane(self.order.data_ptr(), self.row_ptr.data_ptr(), self.tokens.data_ptr(),
+                                             self.ids.data_ptr(), self.n, d_qt.data_ptr(), d_qn.data_ptr(), nq,
+                                             int(k), None if row_mask is None else row_mask.data_ptr(),
+                                             int(mask_stride), bitmap.data_ptr(), out_ids.data_ptr(),
+                                             out_ct.data_ptr(), ctypes.c_void_p(stream)), "crag_tech_lane")
         return out_ids, out_ct
+
+    def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0):
+        """query_token_lists: per query the tokens of extract_tech_tokens(query) (at most 64 queries), any
+        number of tokens per query: the SQL `tech_tokens && :tokens` has no bound either.  The kernel takes 32
+        tokens per query and launch; a longer list (a pasted log with many URLs / hashes) runs in several
+        passes whose hits are merged in the lane's static order.
+        Returns (ids int64 [nq, k] -1 padded, counts int32 [nq]) CUDA tensors, best (most recent) first."""
+        lists = [list(dict.fromkeys(toks)) for toks in query_token_lists]  # distinct, first occurrence kept
+        passes = max(1, max((-(-len(t) // MAX_QUERY_TOKENS) for t in lists), default=1))
+        if passes == 1:
+            return self._pass(lists, k, row_mask, mask_stride, stream)
+        if self._rank_of_id is None:
+            order = self.order.cpu().numpy()
+            ids = self.ids.cpu().numpy()
+            self._rank_of_id = {int(ids[pos]): r for r, pos in enumerate(order)}
+        hits = [set() for _ in lists]
+        for p in range(passes):
+            part = [t[p * MAX_QUERY_TOKENS:(p + 1) * MAX_QUERY_TOKENS] for t in lists]
+            ids_p, ct_p = self._pass(part, k, row_mask, mask_stride, stream)
+            with _on_stream(stream, self.device):
+                ids_h, ct_h = ids_p.cpu().numpy(), ct_p.cpu().numpy()
+            for q in range(len(lists)):
+                hits[q].update(int(v) for v in ids_h[q, :ct_h[q]])
+        out_ids = np.full((len(lists), k), -1, dtype=np.int64)
+        out_ct = np.zeros(len(lists), dtype=np.int32)
+        for q, found in enumerate(hits):
+            best = sorted(found, key=self._rank_of_id.__getitem__)[:k]  # each pass returned ITS first k
+            out_ids[q, :len(best)] = best
+            out_ct[q] = len(best)
+        with _on_stream(stream, self.device):
+            return torch.from_numpy(out_ids).to(self.device), torch.from_numpy(out_ct).to(self.device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -115,21 +157,24 @@ class HybridSearcher:
                  rrf_k: int = DEFAULT_RRF_K) -> None:
         self.index, self.tech = index, tech_index
         self.dense_k, self.tech_k, self.rrf_k = int(dense_k), int(tech_k), int(rrf_k)
-        self._dense_out = None
+        self._dense_out: dict = {}  # per (stream, batch size): results of calls on different streams stay apart
 
     def search(self, query_vectors: torch.Tensor, query_token_lists=None, bm25=None, *, out_k: int = 0,
                row_mask=None, mask_stride: int = 0, stream: int = 0) -> Dict[str, torch.Tensor]:
         """query_vectors [nq, dim] fp32 CUDA; query_token_lists: per query its extract_tech_tokens();
         bm25: (ids int64 [nq, w] CUDA, counts int32 [nq] CUDA) or None; row_mask: packed bits per row
         position (uint8 CUDA), shared (mask_stride 0) or per query.  Returns rrf_fuse's dict plus the dense
-        lane itself ("dense_ids", "dense_scores", "dense_counts")."""
+        lane itself ("dense_ids", "dense_scores", "dense_counts").  Everything is enqueued on `stream`; the
+        dense buffers are reused by the next call with the same stream and batch size (the returned tensors
+        are valid until then), and the caller orders `query_vectors` / `row_mask` / `bm25` with `stream`."""
         nq = int(query_vectors.shape[0])
         dev = query_vectors.device
-        if self._dense_out is None or self._dense_out[0].shape != (nq, self.dense_k):
-            self._dense_out = (torch.empty(nq, self.dense_k, dtype=torch.int64, device=dev),
-                               torch.empty(nq, self.dense_k, dtype=torch.float32, device=dev),
-                               torch.empty(nq, dtype=torch.int32, device=dev))
-        d_ids, d_sc, d_ct = self._dense_out
+        if (stream, nq) not in self._dense_out:
+            with _on_stream(stream, dev):
+                self._dense_out[(stream, nq)] = (torch.empty(nq, self.dense_k, dtype=torch.int64, device=dev),
+                                                 torch.empty(nq, self.dense_k, dtype=torch.float32, device=dev),
+                                                 torch.empty(nq, dtype=torch.int32, device=dev))
+        d_ids, d_sc, d_ct = self._dense_out[(stream, nq)]
         self.index.search_async(query_vectors, self.dense_k, d_ids, d_sc, d_ct, d_row_mask=row_mask,
                                 mask_stride=mask_stride, stream=stream)
         lanes = []

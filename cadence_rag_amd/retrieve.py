@@ -130,10 +130,14 @@ class DenseTable:
 
     def add(self, vectors, columns: Dict[str, Sequence[Any]], call_started_at: Optional[Sequence[Any]] = None,
             call_tags: Optional[Dict[Any, Sequence[str]]] = None) -> None:
+        """Append rows whose ids are ascending and above every stored id (the C ABI's contract); the
+        index grows when its capacity is exhausted.  Rows that may arrive out of id order go through
+        `insert`."""
         n = len(columns[self.id_field])
         if any(len(v) != n for v in columns.values()):
             raise ValueError("all columns must have one entry per vector")
         ids = np.asarray(columns[self.id_field], dtype=np.int64)
+        self._reserve(n)
         self.index.add(vectors, ids=ids)
         for key, vals in columns.items():
             self.columns.setdefault(key, []).extend(list(vals))
@@ -144,6 +148,93 @@ class DenseTable:
         if call_tags:
             self.call_tags.update(call_tags)
         self._pos_of_id = None
+
+    def _reserve(self, n_more: int) -> None:
+        """Make room for n_more rows: the HBM index has a fixed capacity, so a full one is replaced by a
+        larger one (x1.5) and the rows move device-to-device."""
+        need = len(self.index) + int(n_more)
+        if need <= self.index.capacity:
+            return
+        self._rebuild(capacity=max(need, int(self.index.capacity * 1.5) + 1024))
+
+    def _rebuild(self, capacity: int, order: Optional[np.ndarray] = None, extra=None) -> None:
+        """New index of `capacity` rows holding the current rows (+ `extra` = (vectors, ids)), permuted by
+        `order` (positions into the concatenation) when given."""
+        import torch
+        old, n_old = self.index, len(self.index)
+        dev = torch.device("cuda", old.device)
+        new = DenseIndex(old.dim, capacity=capacity, device=old.device)
+        try:
+            if order is None and extra is None:
+                step = 65536
+                for lo in range(0, n_old, step):
+                    m = min(step, n_old - lo)
+                    buf = torch.empty(m, old.dim, dtype=torch.float32, device=dev)
+                    ids = old.get_rows_into(lo, m, buf)
+                    new.add(buf, ids=ids)
+            else:
+                rows = torch.empty(n_old, old.dim, dtype=torch.float32, device=dev)
+                ids = old.get_rows_into(0, n_old, rows) if n_old else np.empty((0,), dtype=np.int64)
+                if extra is not None:
+                    rows = torch.cat([rows, torch.as_tensor(np.asarray(extra[0], dtype=np.float32), device=dev)])
+                    ids = np.concatenate([ids, np.asarray(extra[1], dtype=np.int64)])
+                if order is not None:
+                    rows = rows[torch.as_tensor(order, device=dev)]
+                    ids = ids[order]
+                new.add(rows, ids=ids)
+        except Exception:
+            new.close()
+            raise
+        self.index = new
+        old.close()
+
+    def insert(self, vectors, columns: Dict[str, Sequence[Any]], call_started_at: Optional[Sequence[Any]] = None,
+               call_tags: Optional[Dict[Any, Sequence[str]]] = None) -> None:
+        """`add` for rows in any id order (a row embedded late has an id below the stored maximum): when the
+        new ids do not simply continue the stored ones, the table is rebuilt in ascending id order, which
+        is the order every tie-break of the lane assumes.  An id that is already stored is an error (use
+        DenseIndex.update to re-embed in place)."""
+        new_ids = np.asarray(columns[self.id_field], dtype=np.int64)
+        n = int(new_ids.size)
+        if n == 0:
+            return
+        old_ids = np.asarray(self.columns.get(self.id_field, []), dtype=np.int64)
+        if (old_ids.size == 0 or new_ids.min() > old_ids[-1]) and np.all(np.diff(new_ids) > 0):
+            return self.add(vectors, columns, call_started_at, call_tags)
+        if any(len(v) != n for v in columns.values()):
+            raise ValueError("all columns must have one entry per vector")
+        all_ids = np.concatenate([old_ids, new_ids])
+        order = np.argsort(all_ids, kind="stable")
+        if np.any(np.diff(all_ids[order]) == 0):
+            raise ValueError(f"duplicate {self.id_field} in insert")
+        vec = np.asarray(vectors, dtype=np.float32).reshape(n, -1)
+        self._rebuild(capacity=max(self.index.capacity, all_ids.size), order=order, extra=(vec, new_ids))
+        for key in set(self.columns) | set(columns):
+            merged = list(self.columns.get(key, [None] * old_ids.size)) + list(columns.get(key, [None] * n))
+            self.columns[key] = [merged[i] for i in order]
+        ts = (np.asarray(list(call_started_at), dtype="datetime64[us]") if call_started_at is not None
+              else np.full((n,), np.datetime64("NaT"), dtype="datetime64[us]"))
+        self.call_started_at = np.concatenate([self.call_started_at, ts])[order]
+        self.call_ids = np.concatenate([self.call_ids, np.asarray(list(columns["call_id"]), dtype=object)])[order]
+        if call_tags:
+            self.call_tags.update(call_tags)
+        self._pos_of_id = None
+
+    def sink(self, row_columns):
+        """Backfill sink (embedding_pipeline.BackfillStore.update_embeddings -> HBM): an object whose
+        `add(vectors, ids=...)` asks `row_columns(ids)` for the rows' SELECTed columns — a dict of column
+        lists that may also carry "call_started_at" — and inserts them here, so that the host-side columns,
+        the filter masks and the index stay one table."""
+        table = self
+
+        class _Sink:
+            def add(self, vectors, ids):
+                cols = dict(row_columns(list(ids)))
+                started = cols.pop("call_started_at", None)
+                cols.setdefault(table.id_field, list(ids))
+                table.insert(vectors, cols, call_started_at=started)
+
+        return _Sink()
 
     # -- _build_filter_clause (retrieve.py:93-120) as a row mask --------------------------------
     def filter_mask(self, filters: Optional[RetrieveFilters], call_ids: Optional[Sequence[UUID]]
@@ -197,17 +288,20 @@ class DenseTable:
     @classmethod
     def from_rows(cls, name: str, id_field: str, rows, *, select: Sequence[str], dim: Optional[int] = None,
                   call_tags: Optional[Dict[Any, Sequence[str]]] = None, batch: int = 65536,
-                  device: Optional[int] = None) -> Tuple["DenseTable", List[List[str]]]:
+                  device: Optional[int] = None, headroom: float = 0.25) -> Tuple["DenseTable", List[List[str]]]:
         """Startup loader: `rows` are the mappings of
             SELECT <select>, call_started_at, tech_tokens, embedding FROM <name>
             WHERE embedding IS NOT NULL ORDER BY <id_field>
         with `embedding` in any of pgvector's forms (text literal '[v,...]', binary send/recv bytes, or a
         sequence of floats).  Returns the table and the per-row tech_tokens (for build_tech_lane).  Rows must
-        come in ascending id order so that equal scores resolve to the lower id, as ORDER BY does."""
+        come in ascending id order so that equal scores resolve to the lower id, as ORDER BY does.  The
+        index is allocated with `headroom` spare capacity for the rows ingest / backfill add later (it
+        also grows on demand, see `_reserve`)."""
         from . import vector_io
         rows = list(rows)
         d = dim or settings.embeddings_dim
-        table = cls(name, id_field, dim=d, capacity=max(len(rows), 1), device=device)
+        table = cls(name, id_field, dim=d, capacity=max(int(len(rows) * (1.0 + max(headroom, 0.0))) + 64, 1),
+                    device=device)
         tokens: List[List[str]] = []
         last_id = None
         for lo in range(0, len(rows), batch):

@@ -69,9 +69,12 @@ class ShardedSearch:
         merge_topk_packed(self._gathered, world, nq, k, ids, sc, ct, stream=stream)
         return ids, sc, ct
 
-    def search(self, queries: torch.Tensor, k: int):
-        if (self.index is not None and self._local == self._hip_local and self._merge == self._hip_merge
-                and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+    def search(self, queries: torch.Tensor, k: int, force_exchange: bool = False):
+        """force_exchange: run the all-gather + merge even in a group of one rank (how the RCCL path is
+        exercised on a single-GPU box)."""
+        hip_path = (self.index is not None and self._local == self._hip_local and self._merge == self._hip_merge
+                    and dist.is_initialized())
+        if hip_path and (dist.get_world_size(self.group) > 1 or force_exchange):
             return self._search_packed(queries, k)
         ids, sc, ct = self._local(queries, k)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1

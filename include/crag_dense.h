@@ -53,8 +53,13 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out);
 int crag_index_destroy(crag_index *ix);
 
 /* Append n rows ([n, dim] row-major fp32; host OR device pointer, detected) with their
- * 64-bit ids (NULL => consecutive ids continuing from the current size).  Rows with a zero
- * or non-finite norm are stored but never returned (pgvector gives them a NaN distance).
+ * 64-bit ids (NULL => consecutive ids continuing from the current size).  ids must be strictly
+ * ascending and above every id already stored (CRAG_EINVAL otherwise, nothing is stored): the
+ * backfill feeds rows `ORDER BY id` (embedding_pipeline.py:136), and this is what makes the search
+ * order below "descending score, then ascending id".  A row embedded late (its id below the stored
+ * maximum) goes in through a rebuild: cadence_rag_amd.retrieve.DenseTable.insert does that.
+ * Rows with a zero or non-finite norm are stored but never returned (pgvector gives them a NaN
+ * distance).
  * Replaces: _update_embeddings' per-row UPDATE (embedding_pipeline.py:157-168).
  * Appending is safe while searches enqueued earlier with crag_index_search_async are still running (they
  * never read past the size they were launched with); crag_index_update rewrites rows in place and must
@@ -87,9 +92,9 @@ int crag_index_count_eligible(crag_index *ix, const uint8_t *row_mask, int64_t *
  *   out_ids     [nq, k]  best first; -1 padded
  *   out_scores  [nq, k]  cosine similarity = 1 - (embedding <=> q), clamped to [-1, 1]; NaN padded
  *   out_counts  [nq]     valid entries per query (<= k)
- * Order: descending score; equal scores by ascending row position (insertion order), which is
- * ascending id whenever rows were added in ascending-id order, as the backfill does
- * (`ORDER BY id`, embedding_pipeline.py:136).  The reference SQL has no tie-break at all.
+ * Order: descending score, equal scores by ascending id (crag_index_add keeps ids
+ * ascending with the row position, so the scan breaks ties on the position).  The reference SQL has
+ * no tie-break at all.
  * Replaces: _fetch_chunks_dense / _fetch_artifacts_dense `ORDER BY embedding <=> q LIMIT k`
  * (retrieve.py:339-353, 369-388). */
 int crag_index_search(crag_index *ix, const float *queries, int nq, int k,
@@ -152,6 +157,10 @@ int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint6
 int crag_index_profile_enable(crag_index *ix, int enabled);
 int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
                             double *merge_ms_total);
+
+/* Name of the scan kernel the most recent search on this index launched ("crag::scan_pipe_kernel", ...),
+ * as rocprofv3 prints it; "" before the first search.  For bench.py's roofline object. */
+const char *crag_index_last_scan_kernel(const crag_index *ix);
 
 /* Launch geometry of the scan kernel for the current size (for DESIGN/bench reporting). */
 int crag_index_scan_geometry(const crag_index *ix, int nq, int *workgroups, int *threads,

@@ -1,0 +1,334 @@
+"""GPU tests at the sizes BASELINE.json's configs name (full-size 1M x 1024 scans, the 4B encoder widths,
+the embed_backfill batch shape) and for the boundary rules the C ABI documents (ascending ids, stream
+take-over, pgvector-verbatim fp32 arithmetic).  Everything goes through the C ABI / the product package;
+the oracle is the checker only."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from cadence_rag_amd.dense_index import DenseIndex
+from tests.helpers import assert_topk_matches, unit_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # BASELINE.json: cosine scores within 1e-4 (fp32)
+
+
+# ------------------------------------------------------------------------------------------------------
+# configs[2] / configs[4]: 1M x 1024 (4.1 GB) on one GPU — size-independent properties + sampled oracle
+# ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def million(gpu):
+    """1M x 1024 unit rows generated on the device (seed 1234) with 64 planted near-duplicates, a block of
+    exact duplicates and a few ineligible rows; the host copy feeds the sampled oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 1_000_000
+    g = torch.Generator(device=dev).manual_seed(1234)
+    corpus = torch.empty(n, 1024, dtype=torch.float32, device=dev)
+    for lo in range(0, n, 125_000):
+        blk = torch.randn(125_000, 1024, generator=g, device=dev)
+        corpus[lo:lo + 125_000] = blk / blk.norm(dim=1, keepdim=True)
+    corpus[777_000:777_040] = corpus[5]          # 40 exact duplicates of row 5 far away from it
+    corpus[123_456] = 0.0                        # zero row: never eligible
+    corpus[654_321, 17] = float("nan")           # NaN row: never eligible
+    rng = np.random.default_rng(4321)
+    planted = np.sort(rng.choice(n, size=64, replace=False))
+    planted = planted[~np.isin(planted, [5, 123_456, 654_321]) & ~((planted >= 777_000) & (planted < 777_040))]
+    noise = torch.from_numpy(rng.standard_normal((len(planted), 1024)).astype(np.float32)).to(dev)
+    queries = corpus[torch.from_numpy(planted).to(dev)] + 0.05 * noise / 32.0
+    queries = torch.cat([queries, corpus[5:6] * 2.5,
+                         torch.from_numpy(rng.standard_normal((64 - len(planted) - 1 + 16, 1024)).astype(np.float32)).to(dev)])
+    ix = DenseIndex(1024, capacity=n)
+    ix.add(corpus)
+    host = corpus.cpu().numpy()
+    q_host = queries.cpu().numpy()
+    del corpus
+    torch.cuda.empty_cache()
+    yield ix, host, q_host, planted
+    ix.close()
+
+
+def _sampled_oracle(host, q, k, rows):
+    """fp64 oracle for the query rows `rows` only (a full 1M oracle pass per query is ~1 s of host time)."""
+    oracle.set_threads(16)
+    return oracle.exact_topk(q[rows], host, k, mode=oracle.F64, fast=True)
+
+
+@pytest.mark.parametrize("nq,k", [(32, 10), (64, 10), (64, 100)])
+def test_one_million_rows_properties_and_sampled_oracle(million, nq, k):
+    ix, host, q_all, planted = million
+    q = q_all[:nq]
+    ids, scores, counts = ix.search(q, k)
+    ids2, scores2, counts2 = ix.search(q, k)                   # the reversed pass over the same corpus
+    assert np.array_equal(ids, ids2) and np.array_equal(scores, scores2) and np.array_equal(counts, counts2)
+    assert np.all(counts == k) and np.all(np.diff(scores, axis=1) <= 0)
+    npl = min(nq, len(planted))
+    assert np.array_equal(ids[:npl, 0], planted[:npl])         # every planted neighbour is found first
+    assert not np.isin(ids, [123_456, 654_321]).any()          # zero / NaN rows never come back
+    for row in range(nq):                                      # ids are distinct inside a result
+        assert len(set(ids[row].tolist())) == k
+    sample = [0, nq // 2, nq - 1]
+    want = _sampled_oracle(host, q, k, sample)
+    assert_topk_matches(ids[sample], scores[sample], counts[sample], *want, tol=TOL)
+    recall = np.mean([len(set(ids[r][:10]) & set(want[0][i][:10])) / 10 for i, r in enumerate(sample)])
+    assert recall == 1.0
+    # one query at a time == the batched answer (the 1-query, 32-query and 64-query kernels agree)
+    one = ix.search(q[sample[1]][None], k)
+    assert np.array_equal(one[0][0], ids[sample[1]])
+    assert np.max(np.abs(one[1][0] - scores[sample[1]])) <= 2e-6
+
+
+def test_one_million_rows_exact_duplicates_order_by_id(million):
+    ix, host, q_all, planted = million
+    qi = len(planted)                                          # the query that is 2.5 x row 5
+    ids, scores, counts = ix.search(q_all[qi][None], 50)
+    assert ids[0, 0] == 5 and list(ids[0, 1:41]) == list(range(777_000, 777_040))
+    assert np.all(scores[0, :41] == scores[0, 0])              # bit-identical scores for identical rows
+    # a shared row mask that removes the low half of the duplicates
+    mask = np.ones(1_000_000, dtype=bool)
+    mask[777_000:777_020] = False
+    mask[5] = False
+    ids, _, _ = ix.search(q_all[qi][None], 50, row_mask=DenseIndex.pack_mask(mask))
+    assert list(ids[0, :20]) == list(range(777_020, 777_040))
+    assert ix.count_eligible() == 1_000_000 - 2
+
+
+# ------------------------------------------------------------------------------------------------------
+# boundary rules of include/crag_dense.h
+# ------------------------------------------------------------------------------------------------------
+def test_ids_must_ascend_with_the_row_position(gpu):
+    """ties by ascending id.  The scan breaks ties on the row position, so crag_index_add
+    refuses ids that do not grow with it (host and device pointers), leaving the index unchanged."""
+    import torch
+    rng = np.random.default_rng(2)
+    rows = unit_rows(rng, 64)
+    with DenseIndex(1024, capacity=1000) as ix:
+        ix.add(rows[:10], ids=np.arange(100, 110))
+        for bad in (np.arange(105, 115), np.array([200, 199] + list(range(300, 308))),
+                    np.array([300] * 10), np.arange(109, 119)):
+            with pytest.raises(Exception, match="strictly ascending"):
+                ix.add(rows[10:20], ids=bad.astype(np.int64))
+            with pytest.raises(Exception, match="strictly ascending"):
+                ix.add(torch.from_numpy(rows[10:20]).cuda(), ids=torch.from_numpy(bad.astype(np.int64)).cuda())
+            assert len(ix) == 10
+        with pytest.raises(Exception, match="implicit ids"):
+            ix.add(rows[10:20])                                 # implicit ids would start at 10 <= 109
+        ix.add(rows[10:20], ids=np.arange(110, 120))
+        ix.add(torch.from_numpy(rows[20:30]).cuda(), ids=torch.arange(500, 510).cuda())
+        assert len(ix) == 30
+        got = ix.search(rows[25][None], 3)
+        assert got[0][0, 0] == 505
+        _, stored = ix.get_rows(0, 30)
+        assert stored.tolist() == list(range(100, 120)) + list(range(500, 510))
+
+
+def test_dense_table_insert_out_of_order_rebuilds_in_id_order(gpu):
+    """A row embedded late (id below the stored maximum) goes in through DenseTable.insert; ties then
+    still resolve to the lower id, filters and fetches see the merged table, and the index grows."""
+    from uuid import UUID
+    from cadence_rag_amd import retrieve as rt
+    rng = np.random.default_rng(3)
+    vecs = unit_rows(rng, 300)
+    vecs[250] = vecs[40]                                        # duplicate vectors: ids 1040 and 90
+    table = rt.DenseTable("chunks", "chunk_id", dim=1024, capacity=200)
+    try:
+        def cols(ids):
+            return {"chunk_id": list(ids), "call_id": [UUID(int=1 + (i % 3)) for i in ids],
+                    "speaker": ["S"] * len(ids), "start_ts_ms": [0] * len(ids), "end_ts_ms": [1] * len(ids),
+                    "text": [f"row {i}" for i in ids]}
+        table.add(vecs[:200], cols(range(1000, 1200)))
+        assert table.index.capacity == 200
+        sink = table.sink(lambda ids: cols(ids))
+        sink.add(vecs[200:260].tolist(), ids=list(range(50, 110)))   # late rows: ids BELOW the stored ones
+        sink.add(vecs[260:300].tolist(), ids=list(range(1200, 1240)))  # and a plain append past the capacity
+        assert len(table) == 300 and table.index.capacity >= 300
+        assert table.columns["chunk_id"] == list(range(50, 110)) + list(range(1000, 1240))
+        rows = rt._fetch_chunks_dense(table, vecs[40] * 2.0, None, None, "exact", 5)
+        assert [r["chunk_id"] for r in rows[:2]] == [100, 1040] and rows[0]["text"] == "row 100"
+        assert rows[0]["score"] == rows[1]["score"]
+        f = rt.RetrieveFilters(call_ids=[UUID(int=2)])
+        scoped = rt._fetch_chunks_dense(table, vecs[40], f, f.call_ids, "exact", 128)
+        assert scoped and all(r["call_id"] == UUID(int=2) for r in scoped)
+        assert rt._estimate_dense_candidates(table, "chunks", f, f.call_ids) == sum(
+            1 for i in table.columns["chunk_id"] if 1 + (i % 3) == 2)
+        order = np.argsort(np.r_[np.arange(1000, 1200), np.arange(50, 110), np.arange(1200, 1240)], kind="stable")
+        want = oracle.exact_topk(vecs[7][None], vecs[order], 10, ids=np.asarray(table.columns["chunk_id"]),
+                                 mode=oracle.F64)
+        got = table.index.search(vecs[7][None], 10)
+        assert_topk_matches(*got, *want, tol=TOL)
+        with pytest.raises(ValueError, match="duplicate"):
+            sink.add(vecs[:1].tolist(), ids=[1005])
+    finally:
+        table.close()
+
+
+def test_more_streams_than_workspaces_take_over_behind_events(gpu):
+    """The index keeps 4 search workspaces; a 5th .. 7th stream takes over the least recently used one behind
+    the completion event of its last search.  Seven streams cycling three times, nothing synchronised in
+    between: every answer equals the single-stream answer."""
+    import torch
+    rng = np.random.default_rng(77)
+    n = 40_000
+    corpus = unit_rows(rng, n)
+    shapes = [(64, 10), (33, 50), (5, 10), (64, 100), (1, 128), (32, 10), (40, 64)]
+    qs = [rng.standard_normal((nq, 1024)).astype(np.float32) for nq, _ in shapes]
+    dev = torch.device("cuda", 0)
+    with DenseIndex(1024, capacity=n) as ix:
+        ix.add(corpus)
+        want = [ix.search(q, k) for q, (_, k) in zip(qs, shapes)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(7)]
+        dqs = [torch.from_numpy(q).to(dev) for q in qs]
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(3):
+            for si, st in enumerate(streams):
+                i = (si + 2 * rep) % len(qs)
+                nq, k = shapes[i]
+                o = (torch.empty(nq, k, dtype=torch.int64, device=dev), torch.empty(nq, k, dtype=torch.float32, device=dev),
+                     torch.empty(nq, dtype=torch.int32, device=dev))
+                ix.search_async(dqs[i], k, *o, stream=st.cuda_stream)
+                outs.append((i, o))
+        torch.cuda.synchronize()
+        for i, o in outs:
+            assert np.array_equal(o[0].cpu().numpy(), want[i][0])
+            assert np.array_equal(o[1].cpu().numpy(), want[i][1], equal_nan=True)
+            assert np.array_equal(o[2].cpu().numpy(), want[i][2])
+
+
+def test_add_while_searches_are_in_flight(gpu):
+    """include/crag_dense.h: appending is safe while searches enqueued earlier are still running, because a
+    scan never reads past the size it was launched with."""
+    import torch
+    rng = np.random.default_rng(78)
+    base, extra = unit_rows(rng, 60_000), unit_rows(rng, 2_000)
+    q = rng.standard_normal((64, 1024)).astype(np.float32)
+    extra[:64] = q / np.linalg.norm(q, axis=1, keepdims=True)     # the appended rows would win every query
+    dev = torch.device("cuda", 0)
+    with DenseIndex(1024, capacity=62_000) as ix:
+        ix.add(base)
+        want = ix.search(q, 10)
+        st = torch.cuda.Stream(device=dev)
+        dq = torch.from_numpy(q).to(dev)
+        d_extra = torch.from_numpy(extra).to(dev)
+        torch.cuda.synchronize()
+        outs = []
+        for _ in range(6):
+            o = (torch.empty(64, 10, dtype=torch.int64, device=dev), torch.empty(64, 10, dtype=torch.float32, device=dev),
+                 torch.empty(64, dtype=torch.int32, device=dev))
+            ix.search_async(dq, 10, *o, stream=st.cuda_stream)
+            outs.append(o)
+        ix.add(d_extra)                                           # null stream, while the six scans are queued
+        torch.cuda.synchronize()
+        for o in outs:
+            assert np.array_equal(o[0].cpu().numpy(), want[0]) and np.array_equal(o[1].cpu().numpy(), want[1])
+        after = ix.search(q, 10)
+        assert np.array_equal(after[0][:, 0], np.arange(60_000, 60_064))
+
+
+def test_against_pgvector_verbatim_fp32_arithmetic(gpu):
+    """oracle F32SEQ = pgvector 0.8.1's own arithmetic (sequential fp32 accumulators).  The HIP path sums in
+    another fixed order, so scores differ in the last bits; reported: how many top-10 lists keep pgvector's
+    order, and that every difference is a swap of rows pgvector itself scores within 2e-6 of each other."""
+    rng = np.random.default_rng(2026)
+    n, nq, k = 50_000, 64, 10
+    corpus, q = unit_rows(rng, n), rng.standard_normal((nq, 1024)).astype(np.float32)
+    with DenseIndex(1024, capacity=n) as ix:
+        ix.add(corpus)
+        ids, scores, counts = ix.search(q, k)
+    want = oracle.exact_topk(q, corpus, k, mode=oracle.F32SEQ)
+    same = sum(np.array_equal(ids[i], want[0][i]) for i in range(nq))
+    print(f"\npgvector-verbatim fp32 order reproduced for {same}/{nq} top-{k} lists; "
+          f"max |dscore| = {np.max(np.abs(scores - want[1])):.2e}")
+    assert_topk_matches(ids, scores, counts, *want, tol=TOL)      # only near-tie permutations differ
+    assert same >= nq - 3
+    assert np.max(np.abs(scores - want[1])) <= 5e-6
+
+
+def test_tech_lane_with_more_than_32_query_tokens(gpu):
+    """`tech_tokens && :tokens` has no bound on the query's token count (retrieve.py:183-242); the kernel takes
+    32 per launch, longer lists run in passes merged in the lane's order."""
+    import torch
+    from cadence_rag_amd.fusion import TechTokenIndex
+    rng = np.random.default_rng(9)
+    n = 5000
+    vocab = [f"TOK-{i}" for i in range(400)]
+    row_tokens = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(n)]
+    ids = np.arange(n, dtype=np.int64) * 3 + 7
+    started = np.datetime64("2026-03-01", "us") + rng.integers(0, 40, size=n).astype("timedelta64[D]")
+    queries = [list(rng.choice(vocab, size=m, replace=False)) for m in (70, 33, 5, 0, 100)]
+    queries[1] = queries[1] + queries[1][:4]                     # repeated tokens do not count twice
+    tech = TechTokenIndex(row_tokens, ids, started, torch.device("cuda", 0))
+    got_ids, got_ct = tech.search(queries, 25)
+    order = np.lexsort((ids, -started.astype(np.int64)))
+    for qi, toks in enumerate(queries):
+        want = [int(ids[p]) for p in order if set(row_tokens[p]) & set(toks)][:25]
+        assert got_ids[qi, :int(got_ct[qi])].tolist() == want
+
+
+def test_hybrid_searcher_on_two_side_streams(gpu):
+    """HybridSearcher / TechTokenIndex keep their scratch per stream and allocate on the caller's stream: two
+    side streams sharing one searcher, launched back to back, give the default-stream answers."""
+    import torch
+    from cadence_rag_amd.fusion import HybridSearcher, TechTokenIndex
+    rng = np.random.default_rng(10)
+    n, nq = 20_000, 16
+    corpus = unit_rows(rng, n)
+    vocab = [f"T{i}" for i in range(60)]
+    row_tokens = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(n)]
+    ids = np.arange(n, dtype=np.int64)
+    started = np.datetime64("2026-01-01", "us") + rng.integers(0, 9, size=n).astype("timedelta64[D]")
+    dev = torch.device("cuda", 0)
+    batches = []
+    for b in range(2):
+        qv = torch.from_numpy(rng.standard_normal((nq, 1024)).astype(np.float32)).to(dev)
+        qt = [list(rng.choice(vocab, size=rng.integers(0, 4), replace=False)) for _ in range(nq)]
+        batches.append((qv, qt))
+    with DenseIndex(1024, capacity=n) as index:
+        index.add(corpus, ids=ids)
+        hs = HybridSearcher(index, TechTokenIndex(row_tokens, ids, started, dev), dense_k=30, tech_k=20)
+        want = []
+        for qv, qt in batches:
+            out = hs.search(qv, qt)
+            torch.cuda.synchronize()
+            want.append({key: v.clone() for key, v in out.items()})
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        got = [None, None]
+        for rep in range(3):
+            for b, st in enumerate(streams):
+                got[b] = hs.search(*batches[b], stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for b in range(2):
+            for key in ("ids", "counts", "dense_ids", "dense_counts"):
+                assert torch.equal(got[b][key], want[b][key]), key
+
+
+def test_sharded_search_over_rccl_world_of_one(gpu):
+    """RCCL on hardware: a 1-rank `nccl` group, the packed ResultRecord path forced (one all_gather_into_tensor
+    + crag_merge_topk_packed), against the plain search of the same index."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from cadence_rag_amd.sharded import ShardedSearch
+    rng = np.random.default_rng(55)
+    corpus, q = unit_rows(rng, 30_000), rng.standard_normal((64, 1024)).astype(np.float32)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        with DenseIndex(1024, capacity=30_000) as ix:
+            ix.add(corpus, ids=np.arange(30_000) + 10**10)
+            want = ix.search(q, 10)
+            sh = ShardedSearch(ix)
+            dq = torch.from_numpy(q).to(dev)
+            for _ in range(3):
+                ids, sc, ct = sh.search(dq, 10, force_exchange=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy(), want[0]) and np.array_equal(sc.cpu().numpy(), want[1])
+            assert np.array_equal(ct.cpu().numpy(), want[2])
+    finally:
+        dist.destroy_process_group()
