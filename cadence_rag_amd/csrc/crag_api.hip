@@ -72,8 +72,8 @@ struct DevBuf {  // grow-only device scratch
     }
 };
 
-struct EvTriple {
-    hipEvent_t e0, e1, e2;
+struct EvSet {  // around one profiled search: start, before / after the scan kernel, end
+    hipEvent_t e0, e1, e2, e3;
 };
 
 }  // namespace
@@ -95,20 +95,27 @@ struct crag_index {
         hipStream_t stream = nullptr;
         bool in_use = false;
         DevBuf partial, gbound;
+        // prepared queries (fragment order) and the prefilter path's per-query state
+        DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags;
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
         uint64_t last_use = 0;
     } ws[MAX_WS];
     uint64_t use_clock = 0;
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
-    bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false;
+    bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false;
+    // a stored row whose norm lies outside [1e-30, 1e30]: the fp16 prefilter's error bound assumes normalised
+    // rows in fp32's comfortable range, so such an index always takes the plain fp32 scan
+    bool irregular = false;
+    uint32_t *irregular_dev = nullptr;
+    unsigned long long *pf_stats = nullptr;  // device: candidates, rescored rows, searches (prefilter path)
     const char *last_scan_kernel = "";  // name of the scan kernel the most recent search launched
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
     int pass_parity = 0;  // alternate scan direction between searches (Infinity Cache reuse)
     int profiling = 0;      // 0 = off, N = record HIP events around every N-th search
     int64_t prof_calls = 0;
-    std::vector<EvTriple> ev_pool;
+    std::vector<EvSet> ev_pool;
     size_t ev_used = 0;
 };
 
@@ -140,10 +147,15 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                   hipStream_t st) {
     if (nq <= 0) return CRAG_OK;
     int q_blocks = (nq + 31) / 32;
-    // more than 32 queries and k <= 32: the 64-queries-per-pass kernel (two query blocks per pass)
+    // more than 32 queries: two query blocks share every corpus fragment (64 queries per pass)
     const bool wide = (nq > 32) && !ix->env_no_wide;
     if (wide) q_blocks = ((nq + 63) / 64) * 2;
+    const int nq_pad = q_blocks * 32;
     const int G = scan_groups(ix);
+    // the fp16 prefilter + exact rescoring path needs a few tiles per workgroup for its bounds to form;
+    // small corpora take the plain fp32 scan (they are latency-, not bandwidth-bound anyway)
+    const bool prefilter = !ix->env_no_prefilter && !ix->irregular &&
+                           ix->size >= (int64_t)G * crag::PF_MIN_ROWS_PER_GROUP && (wide || nq <= 32);
     int rc;
     crag_index::Workspace *ws = nullptr;
     for (auto &w : ix->ws)
@@ -173,6 +185,16 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
             HIP_TRY(hipMemsetAsync(ws->gbound.p, 0, ws->gbound.bytes, st));
         }
     }
+    if ((rc = ws->a32.ensure((size_t)nq_pad * crag::DIM * sizeof(float)))) return rc;
+    if ((rc = ws->qinv.ensure((size_t)nq_pad * sizeof(float)))) return rc;
+    const int cap = 8192;  // candidates per query; a fuller list sets the overflow flag -> gated fp32 scan
+    if (prefilter) {
+        if ((rc = ws->a16.ensure((size_t)nq_pad * crag::DIM * 2))) return rc;
+        if ((rc = ws->pf_gbound.ensure((size_t)nq_pad * crag::PF_BOUND_CELLS * sizeof(uint32_t)))) return rc;
+        if ((rc = ws->pf_cand.ensure((size_t)nq_pad * cap * sizeof(uint2)))) return rc;
+        if ((rc = ws->pf_count.ensure((size_t)nq_pad * sizeof(uint32_t)))) return rc;
+        if ((rc = ws->pf_flags.ensure(4 * sizeof(uint32_t)))) return rc;
+    }
 
     // per-workgroup corpus window must stay below the buffer-descriptor / OOB-marker limit
     const int64_t rows_per_g = (ix->size + G - 1) / G + 64;
@@ -180,11 +202,41 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         return fail(CRAG_EINVAL, "index too large for one device scan window (%lld rows)",
                     (long long)ix->size);
 
+    EvSet *ev = nullptr;
+    if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == 0) {
+        if (ix->ev_used == ix->ev_pool.size()) {
+            EvSet t;
+            HIP_TRY(hipEventCreate(&t.e0));
+            HIP_TRY(hipEventCreate(&t.e1));
+            HIP_TRY(hipEventCreate(&t.e2));
+            HIP_TRY(hipEventCreate(&t.e3));
+            ix->ev_pool.push_back(t);
+        }
+        ev = &ix->ev_pool[ix->ev_used++];
+        HIP_TRY(hipEventRecord(ev->e0, st));
+    }
+
+    // K0: 1/||q||, the queries in A-fragment order, reset of the prefilter state
+    crag::PrepParams pp;
+    pp.queries = d_queries;
+    pp.nq = nq;
+    pp.dim = ix->dim;
+    pp.qinv = (float *)ws->qinv.p;
+    pp.a32 = (float *)ws->a32.p;
+    pp.a16 = prefilter ? (_Float16 *)ws->a16.p : nullptr;
+    pp.pf_gbound = prefilter ? (uint32_t *)ws->pf_gbound.p : nullptr;
+    pp.pf_count = prefilter ? (uint32_t *)ws->pf_count.p : nullptr;
+    pp.pf_flags = prefilter ? (uint32_t *)ws->pf_flags.p : nullptr;
+    HIP_TRY(crag::launch_prep_queries(pp, nq_pad, st));
+
     crag::ScanParams sp;
     sp.wide = wide ? 1 : 0;
     sp.corpus = ix->corpus;
     sp.inv_norm = ix->inv_norm;
     sp.queries = d_queries;
+    sp.a32 = (const float *)ws->a32.p;
+    sp.qinv = (const float *)ws->qinv.p;
+    sp.gate = prefilter ? (const uint32_t *)ws->pf_flags.p : nullptr;
     sp.dim = ix->dim;
     sp.mask = (const uint32_t *)d_mask;
     sp.mask_stride_w = mask_stride / 4;
@@ -200,22 +252,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     sp.reverse = ix->pass_parity;
     ix->pass_parity ^= 1;
     if (ix->env_no_reverse) sp.reverse = 0;
-    sp.unpipelined = ix->env_unpipelined ? 1 : 0;
-
-    EvTriple *ev = nullptr;
-    if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == 0) {
-        if (ix->ev_used == ix->ev_pool.size()) {
-            EvTriple t;
-            HIP_TRY(hipEventCreate(&t.e0));
-            HIP_TRY(hipEventCreate(&t.e1));
-            HIP_TRY(hipEventCreate(&t.e2));
-            ix->ev_pool.push_back(t);
-        }
-        ev = &ix->ev_pool[ix->ev_used++];
-        HIP_TRY(hipEventRecord(ev->e0, st));
-    }
-    HIP_TRY(crag::launch_scan(sp, q_blocks, st, &ix->last_scan_kernel));
-    if (ev) HIP_TRY(hipEventRecord(ev->e1, st));
+    sp.unpipelined = (ix->env_unpipelined && !prefilter) ? 1 : 0;
 
     crag::MergeParams mp;
     mp.partial = (const uint2 *)ws->partial.p;
@@ -227,8 +264,56 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     mp.out_counts = d_out_counts;
     mp.k = k;
     mp.G = G;
-    HIP_TRY(crag::launch_merge_partials(mp, nq, st));
-    if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
+
+    if (ev) HIP_TRY(hipEventRecord(ev->e1, st));
+    if (prefilter) {
+        // K1: fp16 scan -> candidates;  K2: the fp32 scan, which exits at once unless a candidate list
+        // overflowed;  K3: exact rescoring + selection (or the merge of K2's lists)
+        crag::PfParams fp;
+        fp.corpus = ix->corpus;
+        fp.inv_norm = ix->inv_norm;
+        fp.a16 = (const _Float16 *)ws->a16.p;
+        fp.qinv = (const float *)ws->qinv.p;
+        fp.mask = (const uint32_t *)d_mask;
+        fp.mask_stride_w = mask_stride / 4;
+        fp.gbound = (uint32_t *)ws->pf_gbound.p;
+        fp.cand = (uint2 *)ws->pf_cand.p;
+        fp.count = (uint32_t *)ws->pf_count.p;
+        fp.flags = (uint32_t *)ws->pf_flags.p;
+        fp.n_rows = ix->size;
+        fp.nq = nq;
+        fp.k = k;
+        fp.G = G;
+        fp.reverse = sp.reverse;
+        fp.sets = k <= 24 ? 1 : (k <= 48 ? 2 : 4);
+        fp.cap = cap;
+        const int nqb = wide ? 2 : 1;
+        HIP_TRY(crag::launch_prefilter(fp, nqb, nq_pad / (32 * nqb), st, &ix->last_scan_kernel));
+        if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
+        HIP_TRY(crag::launch_scan(sp, q_blocks, st, nullptr));
+        crag::FinParams fin;
+        fin.corpus = ix->corpus;
+        fin.inv_norm = ix->inv_norm;
+        fin.a32 = (const float *)ws->a32.p;
+        fin.qinv = (const float *)ws->qinv.p;
+        fin.cand = (const uint2 *)ws->pf_cand.p;
+        fin.count = (const uint32_t *)ws->pf_count.p;
+        fin.flags = (const uint32_t *)ws->pf_flags.p;
+        fin.ids = ix->ids;
+        fin.out_ids = d_out_ids;
+        fin.out_scores = d_out_scores;
+        fin.out_counts = d_out_counts;
+        fin.stats = ix->pf_stats;
+        fin.k = k;
+        fin.cap = cap;
+        fin.merge = mp;
+        HIP_TRY(crag::launch_finalize(fin, nq, st));
+    } else {
+        HIP_TRY(crag::launch_scan(sp, q_blocks, st, &ix->last_scan_kernel));
+        if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
+        HIP_TRY(crag::launch_merge_partials(mp, nq, st));
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev->e3, st));
     HIP_TRY(hipEventRecord(ws->done, st));  // what a stream that later takes this workspace over waits for
     return CRAG_OK;
 }
@@ -319,6 +404,15 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_wide = getenv("CRAG_NO_WIDE") != nullptr;
     ix->env_no_reverse = getenv("CRAG_NO_REVERSE") != nullptr;
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
+    ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
+    if ((e = hipMalloc((void **)&ix->irregular_dev, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->pf_stats, 4 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(ix->irregular_dev, 0, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(ix->pf_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess) {
+        int rc = fail(CRAG_ENOMEM, "hipMalloc for the index state failed: %s", hipGetErrorString(e));
+        crag_index_destroy(ix);
+        return rc;
+    }
     *out = ix;
     return CRAG_OK;
 }
@@ -331,13 +425,23 @@ int crag_index_destroy(crag_index *ix) {
         (void)hipEventDestroy(t.e0);
         (void)hipEventDestroy(t.e1);
         (void)hipEventDestroy(t.e2);
+        (void)hipEventDestroy(t.e3);
     }
+    if (ix->irregular_dev) (void)hipFree(ix->irregular_dev);
+    if (ix->pf_stats) (void)hipFree(ix->pf_stats);
     if (ix->corpus) (void)hipFree(ix->corpus);
     if (ix->inv_norm) (void)hipFree(ix->inv_norm);
     if (ix->ids) (void)hipFree(ix->ids);
     for (auto &w : ix->ws) {
         w.partial.release();
         w.gbound.release();
+        w.a32.release();
+        w.a16.release();
+        w.qinv.release();
+        w.pf_gbound.release();
+        w.pf_cand.release();
+        w.pf_count.release();
+        w.pf_flags.release();
         if (w.done) (void)hipEventDestroy(w.done);
     }
     ix->stage_q.release();
@@ -367,10 +471,15 @@ static int store_rows_locked(crag_index *ix, int64_t pos, const float *rows, int
             HIP_TRY(hipMemcpy(ix->stage_rows.p, src, (size_t)m * ix->dim * sizeof(float), hipMemcpyHostToDevice));
             src = (const float *)ix->stage_rows.p;
         }
-        HIP_TRY(crag::launch_store_rows(src, ix->dim, pos + o, m, ix->corpus, ix->inv_norm, 0));
+        HIP_TRY(crag::launch_store_rows(src, ix->dim, pos + o, m, ix->corpus, ix->inv_norm, ix->irregular_dev, 0));
         if (!dev) HIP_TRY(hipStreamSynchronize(0));  // staging buffer is reused by the next chunk
     }
     HIP_TRY(hipStreamSynchronize(0));
+    if (!ix->irregular) {  // sticky: rows are never removed
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpy(&flag, ix->irregular_dev, sizeof(flag), hipMemcpyDeviceToHost));
+        ix->irregular = flag != 0;
+    }
     return CRAG_OK;
 }
 
@@ -648,17 +757,32 @@ int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms
     DeviceGuard guard(ix->device);
     double scan = 0.0, merge = 0.0;
     for (size_t i = 0; i < ix->ev_used; ++i) {
-        float a = 0.f, b = 0.f;
-        HIP_TRY(hipEventSynchronize(ix->ev_pool[i].e2));
+        float a = 0.f, b = 0.f, c = 0.f;
+        HIP_TRY(hipEventSynchronize(ix->ev_pool[i].e3));
         HIP_TRY(hipEventElapsedTime(&a, ix->ev_pool[i].e0, ix->ev_pool[i].e1));
         HIP_TRY(hipEventElapsedTime(&b, ix->ev_pool[i].e1, ix->ev_pool[i].e2));
-        scan += a;
-        merge += b;
+        HIP_TRY(hipEventElapsedTime(&c, ix->ev_pool[i].e2, ix->ev_pool[i].e3));
+        scan += b;
+        merge += a + c;
     }
     if (n_launches) *n_launches = (int64_t)ix->ev_used;
     if (scan_ms_total) *scan_ms_total = scan;
     if (merge_ms_total) *merge_ms_total = merge;
     ix->ev_used = 0;
+    return CRAG_OK;
+}
+
+int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candidates, int64_t *rescored_rows) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(v, ix->pf_stats, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ix->pf_stats, 0, sizeof(v)));
+    if (candidates) *candidates = (int64_t)v[0];
+    if (rescored_rows) *rescored_rows = (int64_t)v[1];
+    if (searches) *searches = (int64_t)v[2];
     return CRAG_OK;
 }
 

@@ -16,7 +16,10 @@ constexpr int GB_CELLS = 32;                  // global-bound buckets per query 
 struct ScanParams {
     const float *corpus;      // tile32 layout
     const float *inv_norm;    // [cap_rows] 1/||row||, 0 = never eligible
-    const float *queries;     // [nq, dim] row-major fp32 (raw; normalised in-kernel)
+    const float *queries;     // [nq, dim] row-major fp32, raw (only scan_kernel, the A/B baseline, reads them)
+    const float *a32;         // the same queries in A-fragment order, zero padded (prep_queries_kernel)
+    const float *qinv;        // [nq_pad] 1/||q|| (0: zero / non-finite query)
+    const uint32_t *gate;     // nullable; when set and *gate == 0 the scan exits at once (fallback launch)
     int wide;                 // 1: the 64-queries-per-pass kernel (two query blocks per pass)
     const uint32_t *mask;     // nullable; 32 rows per word
     int64_t mask_stride_w;    // words between consecutive queries' masks (0 = shared)
@@ -46,6 +49,55 @@ struct MergeParams {
     int G;
 };
 
+// ---- prefilter path (fp16 MFMA scan + exact rescoring), see crag_search.hip --------------------------------
+constexpr int PF_BOUND_CELLS = 128;           // class maxima per query: 4 sets x 32 row classes
+constexpr int PF_MIN_ROWS_PER_GROUP = 128;    // below this many rows per workgroup the plain fp32 scan is used
+
+struct PrepParams {
+    const float *queries;     // [nq, dim] row-major fp32
+    int nq, dim;
+    float *qinv;              // [nq_pad]
+    float *a32;               // [nq_pad/32][8 waves][16][64] float4: raw queries in fp32 A-fragment order
+    _Float16 *a16;            // nullable; [nq_pad/32][8 waves][8][64][8]: unit queries in fp16 A-fragment order
+    uint32_t *pf_gbound;      // nullable; [nq_pad][PF_BOUND_CELLS], zeroed here
+    uint32_t *pf_count;       // [nq_pad] candidates per query, zeroed here
+    uint32_t *pf_flags;       // [4]: [0] = a candidate list overflowed, zeroed here
+};
+
+struct PfParams {
+    const float *corpus;
+    const float *inv_norm;
+    const _Float16 *a16;
+    const float *qinv;
+    const uint32_t *mask;
+    int64_t mask_stride_w;
+    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS]
+    uint2 *cand;              // [nq_pad][cap]: x = orderable approximate score, y = row position
+    uint32_t *count;          // [nq_pad]
+    uint32_t *flags;
+    int64_t n_rows;
+    int nq, k, G, reverse;
+    int sets;                 // 1, 2 or 4 class sets (<= k)
+    int cap;
+};
+
+struct FinParams {
+    const float *corpus;
+    const float *inv_norm;
+    const float *a32;
+    const float *qinv;
+    const uint2 *cand;
+    const uint32_t *count;
+    const uint32_t *flags;
+    const int64_t *ids;
+    int64_t *out_ids;
+    float *out_scores;
+    int32_t *out_counts;
+    unsigned long long *stats;  // nullable; [0] candidates, [1] rescored rows, [2] searches
+    int k, cap;
+    MergeParams merge;          // used instead when flags[0] != 0 (the gated fp32 scan ran)
+};
+
 struct XMergeParams {
     const int64_t *ids;
     const float *scores;
@@ -61,10 +113,14 @@ struct XMergeParams {
 
 // kernel_name (nullable) receives the name of the kernel that was launched (a string literal)
 hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st, const char **kernel_name);
+hipError_t launch_prep_queries(const PrepParams &p, int nq_pad, hipStream_t st);
+// passes = number of 32*nqb-query passes (grid.y); nqb = 1 or 2
+hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t st, const char **kernel_name);
+hipError_t launch_finalize(const FinParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st);
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
-                             float *inv_norm, hipStream_t st);
+                             float *inv_norm, uint32_t *irregular, hipStream_t st);
 hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
                             hipStream_t st);
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,

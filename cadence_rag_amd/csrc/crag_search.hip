@@ -164,7 +164,8 @@ struct ScanCtx {
     const uint32_t *mrow[2];
 };
 
-__device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p) {
+// row range / lane geometry of one scan workgroup (everything but the query fields)
+__device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int reverse) {
     ScanCtx c;
     c.lane = threadIdx.x & 63;
     c.w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -173,15 +174,23 @@ __device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p) {
     c.j = c.lane & 31;
     c.h = c.lane >> 5;
     // this workgroup's row range, balanced in units of 8 rows (one 128-B line per k-quad)
-    const int64_t n8 = (p.n_rows + 7) >> 3;
-    c.r_begin = ((n8 * c.g) / p.G) << 3;
-    c.r_end = ((n8 * (c.g + 1)) / p.G) << 3;
-    if (c.r_end > p.n_rows) c.r_end = p.n_rows;
+    const int64_t n8 = (n_rows + 7) >> 3;
+    c.r_begin = ((n8 * c.g) / G) << 3;
+    c.r_end = ((n8 * (c.g + 1)) / G) << 3;
+    if (c.r_end > n_rows) c.r_end = n_rows;
     c.t_begin = c.r_begin >> 5;
     const int64_t t_end = (c.r_end > c.r_begin) ? ((c.r_end + 31) >> 5) : c.t_begin;
     c.n_tiles = (int)(t_end - c.t_begin);
-    c.reverse = p.reverse != 0;
+    c.reverse = reverse != 0;
     c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.lane * 16);
+    c.qloc[0] = c.qloc[1] = 0;
+    c.qok[0] = c.qok[1] = false;
+    c.mrow[0] = c.mrow[1] = nullptr;
+    return c;
+}
+
+__device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p) {
+    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
     // after the LDS reduction this wave holds accumulator registers r = 2w, 2w+1 ->
     // query (r&3) + 8*(r>>2) + 4*h of the block, corpus row j of the tile
 #pragma unroll
@@ -576,7 +585,7 @@ __device__ __forceinline__ uint32_t half_min_u32(uint32_t v) {
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     __shared__ float2 slab[2][SCAN_WAVES][8][64];
-    __shared__ double red[SCAN_WAVES][32];  // per-wave partial sums of squares of the 32 queries
+    if (p.gate && *p.gate == 0u) return;  // fallback launch behind the prefilter path: nothing overflowed
     const ScanCtx c = make_ctx(p);
     const int lane = c.lane, w = c.w, j = c.j;
 
@@ -592,37 +601,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
     }
-    // A operand: raw queries, lane (i = lane&31, h = lane>>5) holds q[i][128w + 8s + 4h + 0..3]
+    // A operand: the raw queries in fragment order (prep_queries_kernel), lane (i = lane&31, h = lane>>5) holds
+    // q[i][128w + 8s + 4h + 0..3]: one coalesced 1 KiB load per s
     f32x4 a[16];
     {
-        const int qi = c.qb * 32 + j;
-        const bool have = qi < p.nq;
-        const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
+        const f32x4 *afrag = reinterpret_cast<const f32x4 *>(p.a32) + ((size_t)(c.qb * SCAN_WAVES + w) * 16) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int col = w * KSLICE + 8 * s + 4 * c.h;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (have) {
-                if ((p.dim & 3) == 0) {
-                    if (col < p.dim) v = *reinterpret_cast<const f32x4 *>(qrow + col);
-                } else {
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc)
-                        if (col + cc < p.dim) v[cc] = qrow[col + cc];
-                }
-            }
-            a[s] = v;
-        }
-        // four independent fp64 chains (one per component): a single dependent chain of 64 fp64 FMAs per
-        // wave costs several microseconds of every launch
-        double s4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) s4[cc] += (double)a[s][cc] * (double)a[s][cc];
-        double ss = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        ss += __shfl_xor(ss, 32);
-        if (c.h == 0) red[w][j] = ss;  // read after the first barrier of the tile loop
+        for (int s = 0; s < 16; ++s) a[s] = afrag[s * 64];
     }
     // drain with the compiler's own builtin so its vmcnt scoreboard is empty at the loop head:
     // otherwise the loop-head merge keeps a conservative wait on the A registers in every
@@ -642,7 +627,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     prev.nrow = 0u;
     prev.scale[0] = prev.scale[1] = 0.f;
     prev.tauh[0] = prev.tauh[1] = 0u;
-    float qinv[2] = {0.f, 0.f};  // 1/||q|| of the two owned queries of this half-wave
+    float qinv[2];  // 1/||q|| of the two owned queries of this half-wave (0: zero / non-finite query)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) qinv[e] = c.qok[e] ? p.qinv[c.qb * 32 + c.qloc[e]] : 0.f;
 
     int wbuf = 0;  // slab buffer the tile now being multiplied will be written to
     for (int ti = 0; ti < c.n_tiles; ++ti) {
@@ -680,20 +667,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
             if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
             if constexpr ((m & 1) == 0 && (m >> 1) < PIPE_OPS) {
                 pipe_bg<(m >> 1)>(p, c, slab, wbuf ^ 1, prev, st);
-            }
-            if constexpr (m == 5) {
-                // first tile only: the query norms (their partials were written before barrier 0)
-                if (ti == 0) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        double tot = 0.0;
-#pragma unroll
-                        for (int ww = 0; ww < SCAN_WAVES; ++ww) tot += red[ww][c.qloc[e]];
-                        const bool ok = c.qok[e] && (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
-                        qinv[e] = ok ? (float)(1.0 / sqrt(tot)) : 0.f;
-                        if (!(qinv[e] < 3.0e38f)) qinv[e] = 0.f;
-                    }
-                }
             }
             if constexpr (m == 57) {  // eligibility of this tile's (row, query) pairs, used next tile
                 const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_row > 0.f);
@@ -752,7 +725,6 @@ struct Pipe2Ctx {
 template <int KS, int NQB>
 struct Pipe2Lds {
     float2 slab[3 - NQB][SCAN_WAVES][NQB][8][64];  // 64 KiB split-K partial sums [buf][producer][query block][pair][lane]
-    double red[SCAN_WAVES][NQB][32];               // partial sums of squares of the queries
     uint2 list[SCAN_WAVES][NQB][2][KS][64];        // running top-k lists (keys), one per owned query
     uint2 tinfo[SCAN_WAVES][NQB][2][64];           // per (query, row): x = scale bits, y = global bound
     uint2 kth[SCAN_WAVES][NQB][2][2];              // k-th key of every list, per half-wave
@@ -952,6 +924,7 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
 template <int KS, int NQB>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) {
     __shared__ Pipe2Lds<KS, NQB> L;
+    if (p.gate && *p.gate == 0u) return;  // fallback launch behind the prefilter path: nothing overflowed
     constexpr int RING = NQB == 2 ? 8 : 16;   // B prefetch ring depth (loads in flight per wave)
     constexpr int SLOTS = 64 * NQB;           // MFMAs per tile and wave
     const ScanCtx c = make_ctx(p);  // row range; its query fields are not used here
@@ -980,38 +953,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
 #pragma unroll
     for (int s = 0; s < RING; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + s * 1024, 0, 0);
 
-    // A operand: raw queries of the block(s), lane (i = lane&31, h) holds q[i][128w + 8s + 4h + 0..3];
-    // 1/||q|| is applied to the score later
+    // A operand: the raw queries of the block(s) in fragment order (prep_queries_kernel), lane (i = lane&31, h)
+    // holds q[i][128w + 8s + 4h + 0..3]; 1/||q|| (also prepared) is applied to the score later
     f32x4 a[NQB][16];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
-        const int qi = ((int)blockIdx.y * NQB + qb) * 32 + j;
-        const bool have = qi < p.nq;
-        const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
+        const f32x4 *afrag = reinterpret_cast<const f32x4 *>(p.a32) +
+                             ((size_t)(((int)blockIdx.y * NQB + qb) * SCAN_WAVES + w) * 16) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int col = w * KSLICE + 8 * s + 4 * c.h;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (have) {
-                if ((p.dim & 3) == 0) {
-                    if (col < p.dim) v = *reinterpret_cast<const f32x4 *>(qrow + col);
-                } else {
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc)
-                        if (col + cc < p.dim) v[cc] = qrow[col + cc];
-                }
-            }
-            a[qb][s] = v;
-        }
-        // after all loads are issued: four independent fp64 chains (one per component) instead of one
-        double s4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) s4[cc] += (double)a[qb][s][cc] * (double)a[qb][s][cc];
-        double ss = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-        ss += __shfl_xor(ss, 32);
-        if (c.h == 0) L.red[w][qb][j] = ss;  // combined after the first barrier of the tile loop
+        for (int s = 0; s < 16; ++s) a[qb][s] = afrag[s * 64];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
 #pragma unroll
@@ -1020,7 +970,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
             if ((lane & 31) == 0) {
                 L.kth[w][qb][e][c.h] = make_uint2(0u, 0u);
                 L.pub[w][qb][e][c.h] = 0u;
-                L.qinv[w][qb][e][c.h] = 0.f;
+                L.qinv[w][qb][e][c.h] = c2.qok[qb][e] ? p.qinv[c2.qglob[qb][e]] : 0.f;
             }
         }
     }
@@ -1108,23 +1058,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                 constexpr int o = (m - OPS0) >> 1;
                 if constexpr (o < PIPE_OPS) pipe2_bg<o, 0, NQB, KS>(p, c, c2, L, rbuf, st);
                 else if constexpr (NQB == 2 && o < 2 * PIPE_OPS) pipe2_bg<o - PIPE_OPS, NQB - 1, NQB, KS>(p, c, c2, L, rbuf, st);
-            }
-            if constexpr (m == OPS0 + 3) {
-                // first tile only: the query norms (partials were written before barrier 0)
-                if (ti == 0) {
-#pragma unroll
-                    for (int q2 = 0; q2 < NQB; ++q2)
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            double tot = 0.0;
-#pragma unroll
-                            for (int ww = 0; ww < SCAN_WAVES; ++ww) tot += L.red[ww][q2][c2.qloc[e]];
-                            const bool ok = c2.qok[q2][e] && (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
-                            float qv = ok ? (float)(1.0 / sqrt(tot)) : 0.f;
-                            if (!(qv < 3.0e38f)) qv = 0.f;
-                            if ((lane & 31) == 0) L.qinv[w][q2][e][c.h] = qv;
-                        }
-                }
             }
             if constexpr (NQB == 2 && m == BAR2) {
                 // every wave has finished reading the slab (op 3 of query block 1): second barrier of the tile,
@@ -1219,7 +1152,7 @@ __device__ __forceinline__ int suffix_above(const int *hist, int *wave_tot, int 
     return above;
 }
 
-__global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergeParams p) {
+__device__ __forceinline__ void merge_partials_body(const MergeParams &p, const int q) {
     __shared__ uint64_t cand[MERGE_CAP];
     __shared__ uint64_t win[CRAG_MAX_K_];
     __shared__ __attribute__((aligned(16))) uint64_t heads[MERGE_HEADS + 8];
@@ -1230,7 +1163,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergePara
     __shared__ unsigned long long wave_max[MERGE_THREADS / 64];
     __shared__ int s_digit, s_need;
 
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int qb = q >> 5, ql = q & 31;
     const uint2 *base = p.partial + ((size_t)qb * p.G * 32 + ql) * (size_t)p.k;
     const size_t lstride = (size_t)32 * p.k;  // entries between consecutive workgroups' lists
@@ -1408,6 +1341,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergePara
     if (p.gbound && tid < GB_CELLS) p.gbound[(size_t)q * GB_CELLS + tid] = 0u;
 }
 
+__global__ __launch_bounds__(MERGE_THREADS) void merge_partials_kernel(MergeParams p) { merge_partials_body(p, blockIdx.x); }
+
 // ------------------------------------------------------------------------------------------
 // cross-shard merge (multi-GPU exchange step): [n_lists, nq, k] (ids, scores) -> [nq, k]
 // order: score desc, id asc.  One 256-thread workgroup per query, rank by counting.
@@ -1470,7 +1405,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 // rows [n, dim] row-major -> tile32 layout at row positions [pos, pos+n); also 1/||row||.
 // One 256-thread block per row: thread kq moves dims [4kq, 4kq+3].
 __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int dim, int64_t pos,
-                                                         float *corpus, float *inv_norm) {
+                                                         float *corpus, float *inv_norm, uint32_t *irregular) {
     __shared__ double sh[4];
     const int64_t i = blockIdx.x;
     const int kq = threadIdx.x;
@@ -1494,6 +1429,8 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int 
         float inv = ok ? (float)(1.0 / sqrt(ss)) : 0.f;
         if (!(inv > 0.f) || !(inv < 3.0e38f)) inv = 0.f;
         inv_norm[row] = inv;
+        // a norm far outside fp32's comfortable range: the index is kept off the fp16 prefilter path
+        if (inv > 0.f && (inv < 1.0e-30f || inv > 1.0e30f)) *irregular = 1u;
     }
 }
 
@@ -1527,6 +1464,501 @@ __global__ __launch_bounds__(256) void count_eligible_kernel(const float *inv_no
 __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t first) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) ids[pos + i] = first + i;
+}
+
+// ==========================================================================================
+// Prefilter path: fp16 MFMA scan (HBM-bound for any batch) + exact fp32 rescoring of the survivors
+// ==========================================================================================
+// The fp32 MFMA runs at 1/16 of the fp16 rate, which makes a 64-query pass matrix-pipe bound (4.2).  Here
+// the corpus is streamed ONCE, every fp32 fragment is normalised (x 1/||row||) and rounded to fp16 in
+// registers and multiplied with the fp16 unit queries by v_mfma_f32_32x32x16_f16.  The result is the cosine
+// up to a PROVEN bound delta (rounding both operands to 11 significant bits + fp32 accumulation, see
+// PF_DELTA); a row whose approximate score is within 2*delta of a lower bound on the k-th best approximate
+// score may be in the exact top-k and becomes a candidate, every other row cannot.  finalize_kernel rescoring
+// the (few) candidates with the fixed-order fp32 chain of the scan kernels above gives bit-identical scores
+// and order.  Bytes: the same N*D*4 corpus stream + 4 KiB per rescored row (reported by bench.py).
+//
+// Lower bound on the k-th best approximate score of a query without any sorted list: rows are split into
+// 32*sets classes (row position mod 32 = the lane that owns the row, x tile index mod sets); gbound[q][class]
+// is the best approximate score seen in the class by ANY workgroup (atomic max).  The (k_s)-th largest of the 32
+// class maxima of set s is attained by k_s distinct rows; with sum k_s = k, the minimum over the sets is a
+// valid bound.  Stale reads only prune less.
+constexpr float PF_DELTA = 1.25e-3f;
+// |approx - cos| <= sum_i |q_i c_i| (2u + u^2) [u = 2^-11, fp16 round-to-nearest of both operands, each in
+// [-1, 1] after normalisation]  <= 9.8e-4 by Cauchy-Schwarz, + fp16 subnormal flushes 2 * 32 * 2^-25 = 1.9e-6,
+// + fp32 accumulation of 1024 exact products and 7 partial sums, <= 1031 * 2^-23 = 1.23e-4 even if every add
+// truncates, + the fp32 normalisations 4 * 2^-24; sum 1.105e-3 (the difference between the fp32 chain and the
+// real-number cosine, < 2e-6, included).  tests/test_prefilter_gpu.py measures the actual worst case.
+constexpr int PF_STAGE = 3072;   // per-workgroup candidate staging entries in LDS (flushed above 1024)
+constexpr int PF_MAX_SETS = 4;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- K0: per query 1/||q||, the query in fp32 A-fragment order (raw) and fp16 A-fragment order (unit) --------
+// One 256-thread workgroup per padded query; thread t owns dims 4t .. 4t+3.  Also resets the per-query
+// prefilter state (class maxima, candidate count) and the overflow flag of this workspace.
+__global__ __launch_bounds__(256) void prep_queries_kernel(PrepParams p) {
+    __shared__ double sh[4];
+    const int q = blockIdx.x, t = threadIdx.x;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < p.nq) {
+        const float *src = p.queries + (size_t)q * p.dim;
+        if ((p.dim & 3) == 0) {
+            if (4 * t < p.dim) v = *reinterpret_cast<const f32x4 *>(src + 4 * t);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * t + c < p.dim) v[c] = src[4 * t + c];
+        }
+    }
+    double ss = ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+    ss = block_sum_256(ss, sh);
+    const bool ok = (q < p.nq) && (ss > 0.0) && (ss < 1.0e300) && (ss == ss);
+    float qinv = ok ? (float)(1.0 / sqrt(ss)) : 0.f;
+    if (!(qinv < 3.0e38f)) qinv = 0.f;
+    if (t == 0) p.qinv[q] = qinv;
+    const int qb = q >> 5, i = q & 31, w = t >> 5, d = (4 * t) & 127;
+    {   // fp32 fragments: float4 (s, h) of wave slice w, s = d/8, h = (d/4)&1
+        const int sidx = d >> 3, h = (d >> 2) & 1;
+        reinterpret_cast<f32x4 *>(p.a32)[((size_t)(qb * SCAN_WAVES + w) * 16 + sidx) * 64 + h * 32 + i] = v;
+    }
+    if (p.a16) {  // fp16 fragments of the unit query: k-step t8 = d/16, elements 4g..4g+3 (g = (d/8)&1) of lane (i, h)
+        const int t8 = d >> 4, g = (d >> 3) & 1, h = (d >> 2) & 1;
+        f32x2 lo = {v[0] * qinv, v[1] * qinv}, hi = {v[2] * qinv, v[3] * qinv};
+        const f16x2 l2 = __builtin_convertvector(lo, f16x2), h2 = __builtin_convertvector(hi, f16x2);
+        _Float16 *dst = p.a16 + ((((size_t)(qb * SCAN_WAVES + w) * 8 + t8) * 64 + h * 32 + i) * 8 + 4 * g);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f16x4 *>(dst) = f16x4{l2[0], l2[1], h2[0], h2[1]};
+    }
+    if (p.pf_gbound) {
+        if (t < PF_MAX_SETS * 32) p.pf_gbound[(size_t)q * (PF_MAX_SETS * 32) + t] = 0u;
+        if (t == 0) p.pf_count[q] = 0u;
+        if (q == 0 && t < 4) p.pf_flags[t] = 0u;
+    }
+}
+
+// sort the 32 values of each half-wave, descending with the lane index
+__device__ __forceinline__ uint32_t sort32_desc_u32(uint32_t v, int lane) {
+#define CRAG_CX(X_, BIT_)                                              \
+    {                                                                  \
+        const uint32_t o_ = swz_xor<X_>(v);                            \
+        const bool mx_ = !(lane & BIT_);                               \
+        v = mx_ ? (o_ > v ? o_ : v) : (o_ < v ? o_ : v);               \
+    }
+    CRAG_CX(1, 1) CRAG_CX(3, 2) CRAG_CX(1, 1) CRAG_CX(7, 4) CRAG_CX(2, 2) CRAG_CX(1, 1) CRAG_CX(15, 8) CRAG_CX(4, 4)
+    CRAG_CX(2, 2) CRAG_CX(1, 1) CRAG_CX(31, 16) CRAG_CX(8, 8) CRAG_CX(4, 4) CRAG_CX(2, 2) CRAG_CX(1, 1)
+#undef CRAG_CX
+    return v;
+}
+
+template <int NQB>
+struct PfLds {
+    typedef float slab_t __attribute__((ext_vector_type(2 * NQB)));
+    slab_t slab[2][SCAN_WAVES][SCAN_WAVES][64];  // [buf][owner wave][producer wave][lane]: split-K partial sums
+    uint2 stage[PF_STAGE];                       // staged candidates: x = orderable score, y = (row - window) << 6 | query
+    uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
+    uint32_t n_stage;
+};
+
+// What a wave owns after the split-K reduction: RPO = 2*NQB queries per lane (row j = lane & 31), consecutive
+// indices: register R = w*RPO + e of the concatenated accumulators is query (R>>4)*32 + (r&3) + 8*(r>>2) + 4h
+// with r = R & 15, and w*RPO is a multiple of RPO, so (r & 3) = e (+2 for odd w when RPO = 2).
+template <int NQB>
+struct PfOwner {
+    int ql0;            // first owned query inside the pass; the others are ql0 + e
+    int qg0;            // ... and as a global query index
+    uint32_t okmask;    // bit e: owned query e is a real query with a finite non-zero norm
+};
+
+// candidates of one tile -> LDS staging.  sc: approximate cosines (NaN = not eligible), pass: candidate predicate
+template <int NQB>
+__device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, const float (&sc)[2 * NQB],
+                                         const bool (&pass)[2 * NQB], uint32_t row_in_window, uint32_t *flags) {
+#pragma unroll
+    for (int e = 0; e < 2 * NQB; ++e) {
+        if (pass[e]) {
+            const uint32_t slot = atomicAdd(&L.n_stage, 1u);
+            if (slot < (uint32_t)PF_STAGE) {
+                atomicAdd(&L.qcount[o.ql0 + e], 1u);
+                L.stage[slot] = make_uint2(f2ord(sc[e]), (row_in_window << 6) | (uint32_t)(o.ql0 + e));
+            } else {
+                *flags = 1u;  // cannot happen (<= 1024 staged + <= 2048 per tile); never drop a candidate silently
+            }
+        }
+    }
+}
+
+// staged candidates -> the per-query global lists (all threads of the workgroup; contains barriers)
+template <int NQB>
+__device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64_t window_row0) {
+    __syncthreads();
+    const uint32_t n = L.n_stage < (uint32_t)PF_STAGE ? L.n_stage : (uint32_t)PF_STAGE;
+    const int tid = threadIdx.x;
+    if (tid < 32 * NQB) {
+        const uint32_t cnt = L.qcount[tid];
+        const int qg = (int)blockIdx.y * (32 * NQB) + tid;
+        L.qbase[tid] = cnt ? atomicAdd(&p.count[qg], cnt) : 0u;
+        L.qcount[tid] = 0u;
+        L.qfill[tid] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += SCAN_THREADS) {
+        const uint2 e = L.stage[i];
+        const uint32_t ql = e.y & 63u;
+        const uint32_t pos = L.qbase[ql] + atomicAdd(&L.qfill[ql], 1u);
+        const int qg = (int)blockIdx.y * (32 * NQB) + (int)ql;
+        if (pos < (uint32_t)p.cap) {
+            p.cand[(size_t)qg * p.cap + pos] = make_uint2(e.x, (uint32_t)(window_row0 + (int64_t)(e.y >> 6)));
+        } else {
+            p.flags[0] = 1u;  // this query's list is full: the exact scan behind us takes over
+        }
+    }
+    __syncthreads();
+    if (tid == 0) L.n_stage = 0u;
+    __syncthreads();
+}
+
+// ---- K1: the fp16 scan.  Grid (G, passes); one pass = 32*NQB queries against this workgroup's row range ------
+template <int NQB, int SETS>
+__global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
+    constexpr int RPO = 2 * NQB;
+    __shared__ PfLds<NQB> L;
+    const ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
+    const int lane = c.lane, w = c.w, j = c.j, h = c.h;
+
+    PfOwner<NQB> o;
+    {
+        const int R = w * RPO, qb = R >> 4, r = R & 15;
+        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
+        o.okmask = 0u;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            if (o.qg0 + e < p.nq && p.qinv[o.qg0 + e] > 0.f) o.okmask |= 1u << e;
+    }
+    if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) L.n_stage = 0u;
+
+    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
+    u32x4 b[16];
+    {
+        const uint32_t v0 = tile_voff(c, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+    }
+    // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
+    // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
+    f16x8 a[NQB][8];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const f16x8 *af = reinterpret_cast<const f16x8 *>(p.a16) +
+                          ((size_t)(((int)blockIdx.y * NQB + qb) * SCAN_WAVES + w) * 8) * 64 + lane;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
+    }
+    float stash[RPO];  // the first tile's scores (NaN = not eligible): judged at the end, when bounds exist
+#pragma unroll
+    for (int e = 0; e < RPO; ++e) stash[e] = __uint_as_float(0x7fc00000u);
+    uint32_t stash_row = 0u;
+    float inv_cur = 0.f;
+    if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
+    __syncthreads();
+
+    // k_s of set s: the (k_s)-th largest class maximum of the set is reached by k_s distinct rows (SETS <= k)
+    const int k_base = p.k / SETS, k_rem = p.k % SETS;
+    const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
+
+    // class maxima of the owned queries, device-coherent loads (they are updated by every workgroup)
+    auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+#pragma unroll
+            for (int s = 0; s < SETS; ++s)
+                gb[e][s] = ((o.okmask >> e) & 1u)
+                               ? __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0u;
+    };
+    // candidate thresholds of the owned queries: min over the sets of the (k_s)-th largest class maximum, - 2 delta
+    auto thresholds = [&](const uint32_t (&gb)[RPO][SETS], float (&thr)[RPO]) {
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) {
+            uint32_t tau = 0xffffffffu;
+#pragma unroll
+            for (int s = 0; s < SETS; ++s) {
+                const uint32_t sorted = sort32_desc_u32(gb[e][s], lane);
+                const int ks = k_base + (s < k_rem ? 1 : 0);
+                const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
+                tau = kth < tau ? kth : tau;
+            }
+            thr[e] = tau == 0u ? -__builtin_inff() : ord2f(tau) - 2.f * PF_DELTA;
+        }
+    };
+
+    int buf = 0;
+    for (int ti = 0; ti < c.n_tiles; ++ti) {
+        const uint32_t vnext = tile_voff(c, ti + 1);
+        const int64_t tile = c.t_begin + tile_of(c, ti);
+        const int64_t row = tile * 32 + j;
+        // operands of this tile's epilogue: issued behind the B loads of this tile (already in flight) and in
+        // front of the next tile's, so they have arrived when the MFMA phase ends
+        float inv_nxt = 0.f;
+        if (ti + 1 < c.n_tiles) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1)) * 32 + j];
+        uint32_t mword[RPO], gb[RPO][SETS];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
+                              : 0xffffffffu;
+        load_bounds(gb);
+
+        f32x16 acc[NQB];
+        static_for<0, 8>([&](auto T) {
+            constexpr int t8 = decltype(T)::value;
+            // two loads = dims {16 t8 + 4h + 0..3} and {16 t8 + 8 + 4h + 0..3} of row j: normalise, round to fp16
+            const f32x4 lo = __builtin_bit_cast(f32x4, b[2 * t8]) * inv_cur;
+            const f32x4 hi = __builtin_bit_cast(f32x4, b[2 * t8 + 1]) * inv_cur;
+            const f16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), f16x2);
+            const f16x2 p1 = __builtin_convertvector((f32x2{lo[2], lo[3]}), f16x2);
+            const f16x2 p2 = __builtin_convertvector((f32x2{hi[0], hi[1]}), f16x2);
+            const f16x2 p3 = __builtin_convertvector((f32x2{hi[2], hi[3]}), f16x2);
+            const f16x8 bf = f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qb][t8], bf, t8 == 0 ? zero16 : acc[qb], 0, 0, 0);
+            b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8) * 1024, 0, 0);
+            b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // split-K: owner wave ow gets registers [ow*RPO, ow*RPO+RPO) of every producer
+#pragma unroll
+        for (int ow = 0; ow < SCAN_WAVES; ++ow) {
+            typename PfLds<NQB>::slab_t v;
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) v[e] = acc[(ow * RPO + e) >> 4][(ow * RPO + e) & 15];
+            L.slab[buf][ow][w][lane] = v;
+        }
+        // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
+        if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        float sc[RPO], thr[RPO];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SCAN_WAVES; ++ww) {
+            const typename PfLds<NQB>::slab_t v = L.slab[buf][w][ww][lane];
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) sc[e] += v[e];
+        }
+        buf ^= 1;
+        thresholds(gb, thr);
+        const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
+        const int set = (int)(tile & (int64_t)(SETS - 1));
+        bool pass[RPO];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) {
+            const bool ok = row_ok && ((o.okmask >> e) & 1u) && ((mword[e] >> j) & 1u) && (sc[e] == sc[e]);
+            sc[e] = ok ? sc[e] : __uint_as_float(0x7fc00000u);
+            // publish an improved class maximum (rare: only a row that beats everything seen in its class)
+            uint32_t seen = gb[e][0];
+#pragma unroll
+            for (int s = 1; s < SETS; ++s) seen = (s == set) ? gb[e][s] : seen;
+            if (ok && f2ord(sc[e]) > seen)
+                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, f2ord(sc[e]), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            pass[e] = sc[e] >= thr[e];
+        }
+        if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
+            stash_row = (uint32_t)(row - c.t_begin * 32);
+        } else {
+            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
+        }
+        inv_cur = inv_nxt;
+    }
+    if (c.n_tiles > 0) {  // the first tile against the final bounds
+        if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        uint32_t gb[RPO][SETS];
+        float thr[RPO];
+        load_bounds(gb);
+        thresholds(gb, thr);
+        bool pass[RPO];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
+        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
+    }
+    pf_flush<NQB>(p, L, c.t_begin * 32);
+}
+
+// ---- K3: candidates -> exact top-k.  One 256-thread workgroup per query ---------------------------------------
+// 1. the k-th largest approximate score among the candidates is the k-th largest over ALL rows (every row of the
+//    approximate top-k passed its threshold); rows below it by more than 2*delta cannot be in the exact top-k.
+// 2. the survivors are rescored exactly: 8 lanes per row redo the scan kernels' arithmetic -- per 128-dim slice
+//    the fmaf chain of v_mfma_f32_32x32x2_f32 in the kernels' k order, the 8 slice sums added in wave order,
+//    x (1/||row|| * 1/||q||), clamp -- so scores and order are bit-identical to the fp32 scan.
+// 3. rank by counting among the exact keys.
+// When the prefilter scan reported an overflow the gated fp32 scan has filled p.partial instead: merge that.
+constexpr int FIN_ROUND = 2048;             // candidates examined per round
+constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
+
+__device__ __forceinline__ float exact_slice_dot(const f32x4 *afrag /* + sub*16*64 + (h*32+i) applied by caller */,
+                                                 const f32x4 *ctile /* tile base + sub slice */, int jrow) {
+    // slice `sub` of the 1024 dims: s = 0..15, then component, then lane half (k = 0, 1 of one 32x32x2 MFMA)
+    float acc = 0.f;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 q0 = afrag[(s * 64)], q1 = afrag[(s * 64) + 32];
+        const f32x4 c0 = ctile[(2 * s) * 32 + jrow], c1 = ctile[(2 * s + 1) * 32 + jrow];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            acc = __builtin_fmaf(q0[cc], c0[cc], acc);
+            acc = __builtin_fmaf(q1[cc], c1[cc], acc);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
+    __shared__ uint64_t best[FIN_BEST];
+    __shared__ int hist[256];
+    __shared__ int wave_tot[MERGE_THREADS / 64];
+    __shared__ int s_digit, s_need, s_nbest, s_rescored;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (p.flags[0] != 0u) {  // uniform over the grid
+        merge_partials_body(p.merge, q);
+        return;
+    }
+    const int k = p.k;
+    const uint32_t total = p.count[q];
+    const int C = (int)(total < (uint32_t)p.cap ? total : (uint32_t)p.cap);
+    const uint2 *cand = p.cand + (size_t)q * p.cap;
+
+    // 1. k-th largest approximate score (radix select over the 32-bit orderable scores, 4 x 8 bits)
+    uint32_t thr_ord = 0u;
+    if (C > k) {
+        uint32_t prefix = 0u, pmask = 0u;
+        int need = k;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int e = tid; e < C; e += MERGE_THREADS) {
+                const uint32_t o = cand[e].x;
+                if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            {
+                const int above = suffix_above(hist, wave_tot, tid);
+                const int here = hist[tid];
+                if (above < need && above + here >= need) {
+                    s_digit = tid;
+                    s_need = need - above;
+                }
+            }
+            __syncthreads();
+            prefix |= (uint32_t)s_digit << shift;
+            pmask |= 255u << shift;
+            need = s_need;
+            __syncthreads();
+        }
+        const float kth = ord2f(prefix);
+        thr_ord = f2ord(kth - 2.f * PF_DELTA);
+    }
+    if (tid == 0) {
+        s_nbest = 0;
+        s_rescored = 0;
+    }
+    __syncthreads();
+
+    // 2. exact rescoring, 8 lanes per candidate, in rounds of FIN_ROUND candidates
+    const int grp = tid >> 3, sub = tid & 7;  // 32 candidates per sweep; lane `sub` = K slice (the scan's wave w)
+    const int qb = q >> 5, qi = q & 31;
+    const float qinv = p.qinv[q];
+    for (int r0 = 0; r0 < C; r0 += FIN_ROUND) {
+        const int rn = (C - r0) < FIN_ROUND ? (C - r0) : FIN_ROUND;
+        for (int e0 = 0; e0 < rn; e0 += 32) {
+            const int e = e0 + grp;
+            bool live = false;
+            uint32_t row = 0u;
+            if (e < rn) {
+                const uint2 ce = cand[r0 + e];
+                live = ce.x >= thr_ord;
+                row = ce.y;
+            }
+            float part = 0.f;
+            if (live) {
+                const f32x4 *afrag = reinterpret_cast<const f32x4 *>(p.a32) + ((size_t)(qb * SCAN_WAVES + sub) * 16) * 64 + qi;
+                const f32x4 *ctile = reinterpret_cast<const f32x4 *>(p.corpus + (size_t)(row >> 5) * TILE_FLOATS) + (size_t)sub * 32 * 32;
+                part = exact_slice_dot(afrag, ctile, (int)(row & 31u));
+            }
+            // the 8 slice sums in wave order 0..7 (the scan kernels' split-K reduction order)
+            float d = __shfl(part, (tid & 63 & ~7) | 0);
+#pragma unroll
+            for (int ww = 1; ww < 8; ++ww) d += __shfl(part, (tid & 63 & ~7) | ww);
+            if (live && sub == 0) {
+                const float inv_row = p.inv_norm[row];
+                const float scale = inv_row * qinv;
+                float sc = d * scale;
+                sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);
+                if (scale > 0.f && sc == sc) {
+                    const uint32_t u = __float_as_uint(sc);
+                    const uint32_t ord = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+                    const int slot = atomicAdd(&s_nbest, 1);
+                    best[slot] = mk64(ord, ~row);
+                }
+                atomicAdd(&s_rescored, 1);
+            }
+        }
+        __syncthreads();
+        if (r0 + FIN_ROUND < C && s_nbest > k) {  // more rounds follow: keep only the running top-k
+            const int B = s_nbest;
+            uint64_t mine[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
+            int rank[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
+            int n_mine = 0;
+            for (int e = tid; e < B; e += MERGE_THREADS) {
+                const uint64_t m = best[e];
+                int rk = 0;
+                for (int i = 0; i < B; ++i) rk += (best[i] > m) ? 1 : 0;
+                mine[n_mine] = m;
+                rank[n_mine++] = rk;
+            }
+            __syncthreads();
+            for (int e = 0; e < n_mine; ++e)
+                if (rank[e] < k) best[rank[e]] = mine[e];
+            if (tid == 0) s_nbest = k;
+            __syncthreads();
+        }
+    }
+
+    // 3. rank by counting among the exact keys
+    const int B = s_nbest;
+    const int count = B < k ? B : k;
+    for (int e = tid; e < B; e += MERGE_THREADS) {
+        const uint64_t mine = best[e];
+        int rank = 0;
+        for (int i = 0; i < B; ++i) rank += (best[i] > mine) ? 1 : 0;
+        if (rank < k) {
+            const uint32_t row = ~(uint32_t)(mine & 0xffffffffull);
+            p.out_scores[(size_t)q * k + rank] = ord2f((uint32_t)(mine >> 32));
+            p.out_ids[(size_t)q * k + rank] = p.ids ? p.ids[row] : (int64_t)row;
+        }
+    }
+    for (int r = count + tid; r < k; r += MERGE_THREADS) {
+        p.out_scores[(size_t)q * k + r] = __uint_as_float(0x7fc00000u);
+        p.out_ids[(size_t)q * k + r] = -1;
+    }
+    if (tid == 0) {
+        p.out_counts[q] = count;
+        if (p.stats) {  // candidates / rescored rows / searches, for bench.py's byte accounting
+            atomicAdd(&p.stats[0], (unsigned long long)total);
+            atomicAdd(&p.stats[1], (unsigned long long)s_rescored);
+            if (q == 0) atomicAdd(&p.stats[2], 1ull);
+        }
+    }
 }
 
 // number of positions i in [0, n) whose id is not greater than its predecessor's (ids[-1] = prev)
@@ -1574,6 +2006,38 @@ hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st, const 
     return hipGetLastError();
 }
 
+hipError_t launch_prep_queries(const PrepParams &p, int nq_pad, hipStream_t st) {
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(nq_pad), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t st, const char **kernel_name) {
+    const dim3 grid(p.G, passes), block(SCAN_THREADS);
+    const char *name = "";
+#define CRAG_LAUNCH(...)                                             \
+    do {                                                              \
+        name = "crag::" #__VA_ARGS__;                                 \
+        hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, p);     \
+    } while (0)
+    if (nqb == 2) {
+        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<2, 1>);
+        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<2, 2>);
+        else CRAG_LAUNCH(prefilter_kernel<2, 4>);
+    } else {
+        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<1, 1>);
+        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<1, 2>);
+        else CRAG_LAUNCH(prefilter_kernel<1, 4>);
+    }
+#undef CRAG_LAUNCH
+    if (kernel_name) *kernel_name = name;
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const FinParams &p, int nq, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st) {
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, p);
     return hipGetLastError();
@@ -1585,10 +2049,10 @@ hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st) {
 }
 
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
-                             float *inv_norm, hipStream_t st) {
+                             float *inv_norm, uint32_t *irregular, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, rows, dim, pos, corpus,
-                       inv_norm);
+                       inv_norm, irregular);
     return hipGetLastError();
 }
 

@@ -197,6 +197,13 @@ class DenseIndex:
                                                         ctypes.byref(merge)), "profile_read")
         return int(n.value), float(scan.value), float(merge.value)
 
+    def prefilter_stats(self) -> dict:
+        """Searches / candidates / exactly rescored rows of the prefilter path since the last call."""
+        a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        _native.check(self._lib.crag_index_prefilter_stats(self._h, ctypes.byref(a), ctypes.byref(b),
+                                                           ctypes.byref(c)), "prefilter_stats")
+        return {"searches": a.value, "candidates": b.value, "rescored_rows": c.value}
+
     def last_scan_kernel(self) -> str:
         """Name of the scan kernel the most recent search launched (as rocprofv3 prints it)."""
         name = self._lib.crag_index_last_scan_kernel(self._h)

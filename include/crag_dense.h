@@ -153,10 +153,17 @@ int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint6
 /* Live kernel timing for bench.py's roofline: enabled = N > 0 records HIP events around the scan
  * (and merge) kernel of every N-th search, on the stream it is launched on (N = 1: every search;
  * larger N perturbs the timed region less); 0 disables.  crag_index_profile_read sums and clears
- * the recorded samples (synchronises the events); n_launches = number of samples. */
+ * the recorded samples (synchronises the events); n_launches = number of samples; scan_ms_total = the scan
+ * kernel alone, merge_ms_total = everything else of a search (query preparation, rescoring / merge). */
 int crag_index_profile_enable(crag_index *ix, int enabled);
 int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
                             double *merge_ms_total);
+
+/* Byte accounting of the prefilter path (fp16 MFMA scan + exact fp32 rescoring of the candidates, the path
+ * searches over corpora of >= 128 rows per workgroup take): sums since the last call, then cleared.
+ * candidates = rows that passed the proven-bound filter, rescored_rows = rows re-read (4 KiB each) for the
+ * exact fp32 score.  Synchronises the device. */
+int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candidates, int64_t *rescored_rows);
 
 /* Name of the scan kernel the most recent search on this index launched ("crag::scan_pipe_kernel", ...),
  * as rocprofv3 prints it; "" before the first search.  For bench.py's roofline object. */

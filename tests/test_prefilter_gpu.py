@@ -1,0 +1,174 @@
+"""The fp16-prefilter + exact-rescoring search path (crag_search.hip: prefilter_kernel / finalize_kernel) against
+the plain fp32 scan of the same library (CRAG_NO_PREFILTER=1) — bit for bit — and against the CPU oracle, on
+inputs built to stress the proven error bound, the candidate lists and the overflow fallback."""
+import numpy as np
+import pytest
+
+import oracle
+from cadence_rag_amd.dense_index import DenseIndex
+from tests.helpers import assert_topk_matches, unit_rows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _index(corpus, monkeypatch, prefilter=True, ids=None):
+    if prefilter:
+        monkeypatch.delenv("CRAG_NO_PREFILTER", raising=False)
+    else:
+        monkeypatch.setenv("CRAG_NO_PREFILTER", "1")   # read once, when the index is created
+    ix = DenseIndex(corpus.shape[1], capacity=len(corpus))
+    ix.add(corpus, ids=ids)
+    return ix
+
+
+def _both(corpus, q, k, monkeypatch, mask=None):
+    packed = None if mask is None else DenseIndex.pack_mask(mask)
+    out = []
+    for pf in (True, False):
+        ix = _index(corpus, monkeypatch, prefilter=pf)
+        try:
+            res = [ix.search(q, k, row_mask=packed) for _ in range(2)]   # forward and reversed pass
+            assert "prefilter" in ix.last_scan_kernel() if pf else "prefilter" not in ix.last_scan_kernel()
+            for a, b in zip(res[0], res[1]):
+                assert np.array_equal(a, b, equal_nan=True)
+            out.append(res[0])
+        finally:
+            ix.close()
+    return out
+
+
+@pytest.mark.parametrize("n,nq,k", [(40_000, 64, 10), (40_000, 1, 10), (50_001, 32, 10), (45_000, 33, 50),
+                                    (60_000, 64, 100), (33_000, 7, 128), (70_000, 100, 24), (36_000, 64, 25)])
+def test_prefilter_path_equals_fp32_scan_bit_for_bit(gpu, monkeypatch, n, nq, k):
+    rng = np.random.default_rng(n + nq * 7 + k)
+    corpus = unit_rows(rng, n) * rng.uniform(0.05, 20.0, (n, 1)).astype(np.float32)   # raw rows, any scale
+    q = rng.standard_normal((nq, 1024)).astype(np.float32) * 3.0
+    new, old = _both(corpus, q, k, monkeypatch)
+    assert np.array_equal(new[0], old[0])                       # same ids, same order
+    assert np.array_equal(new[1], old[1], equal_nan=True)       # the rescoring redoes the scan's fp32 chain exactly
+    assert np.array_equal(new[2], old[2])
+    want = oracle.exact_topk(q[:4], corpus, k, mode=oracle.F64, fast=True)
+    assert_topk_matches(new[0][:4], new[1][:4], new[2][:4], *want, tol=TOL)
+
+
+@pytest.mark.parametrize("frac,per_query,nq,k", [(0.5, True, 64, 10), (0.02, True, 40, 50), (0.3, False, 32, 10),
+                                                 (0.0005, True, 64, 10)])
+def test_prefilter_path_with_row_masks(gpu, monkeypatch, frac, per_query, nq, k):
+    rng = np.random.default_rng(int(frac * 1e4) + nq)
+    n = 48_000
+    corpus = unit_rows(rng, n)
+    q = rng.standard_normal((nq, 1024)).astype(np.float32)
+    mask = rng.random((nq, n) if per_query else (n,)) < frac
+    new, old = _both(corpus, q, k, monkeypatch, mask=mask)
+    for a, b in zip(new, old):
+        assert np.array_equal(a, b, equal_nan=True)
+    m8 = np.packbits(mask[:3] if per_query else mask, axis=-1, bitorder="little")
+    want = oracle.exact_topk(q[:3], corpus, k, mask=m8, mode=oracle.F64, fast=True)
+    assert_topk_matches(new[0][:3], new[1][:3], new[2][:3], *want, tol=TOL)
+
+
+def test_contiguous_scope_mask_like_a_date_range(gpu, monkeypatch):
+    """A date filter on a time-ordered table selects a contiguous row range that a single workgroup may own:
+    the bounds must still form (they are kept per row class, not per workgroup)."""
+    rng = np.random.default_rng(8)
+    n = 80_000
+    corpus = unit_rows(rng, n)
+    q = rng.standard_normal((64, 1024)).astype(np.float32)
+    mask = np.zeros(n, dtype=bool)
+    mask[41_000:41_300] = True          # 300 rows: inside one workgroup's range
+    mask[70_000:70_020] = True
+    new, old = _both(corpus, q, 10, monkeypatch, mask=mask)
+    for a, b in zip(new, old):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert set(new[0].ravel().tolist()) <= set(range(41_000, 41_300)) | set(range(70_000, 70_020))
+
+
+def test_dense_near_ties_stress_the_error_bound(gpu, monkeypatch):
+    """Thousands of rows whose true cosines to the queries lie within a few 1e-4 of each other around the k-th
+    best: a prefilter whose error bound were too optimistic would drop true neighbours here.  Rows are built to
+    bias fp16 rounding (components just below rounding boundaries)."""
+    rng = np.random.default_rng(77)
+    n, d = 40_000, 1024
+    base = rng.standard_normal(d).astype(np.float32)
+    base /= np.linalg.norm(base)
+    corpus = unit_rows(rng, n)
+    cluster = base[None, :] + 2e-3 * rng.standard_normal((6000, d)).astype(np.float32)
+    # push every component towards the upper end of its fp16 rounding interval (worst-case one-sided error)
+    h = cluster.astype(np.float16).astype(np.float32)
+    ulp = np.abs(np.spacing(cluster.astype(np.float16)).astype(np.float32))
+    cluster = (h + 0.499 * ulp * np.sign(h)).astype(np.float32)
+    corpus[10_000:16_000] = cluster
+    q = np.stack([base, base + 1e-3 * rng.standard_normal(d).astype(np.float32), -base] +
+                 [rng.standard_normal(d).astype(np.float32) for _ in range(29)])
+    for k in (10, 100):
+        new, old = _both(corpus, q, k, monkeypatch)
+        for a, b in zip(new, old):
+            assert np.array_equal(a, b, equal_nan=True)
+        want = oracle.exact_topk(q[:3], corpus, k, mode=oracle.F64, fast=True)
+        assert_topk_matches(new[0][:3], new[1][:3], new[2][:3], *want, tol=TOL)
+
+
+def test_candidate_overflow_falls_back_to_the_exact_scan(gpu, monkeypatch):
+    """20 000 identical rows (boilerplate chunks embed identically): every one of them is within the bound of
+    the k-th best, the candidate list (8192 per query) overflows, the gated fp32 scan takes over: the answer
+    is the first k duplicates by id, as the oracle says."""
+    rng = np.random.default_rng(5)
+    n = 60_000
+    corpus = unit_rows(rng, n)
+    corpus[20_000:40_000] = corpus[7]
+    q = np.stack([corpus[7] * 2.0] + [rng.standard_normal(1024).astype(np.float32) for _ in range(39)])
+    ix = _index(corpus, monkeypatch)
+    try:
+        ids, scores, counts = ix.search(q, 10)
+        assert "prefilter" in ix.last_scan_kernel()
+        assert ids[0].tolist() == [7] + list(range(20_000, 20_009))
+        assert np.all(scores[0] == scores[0, 0])
+        stats = ix.prefilter_stats()
+        assert stats["searches"] == 0           # the finalize kernel merged the fp32 scan's lists instead
+        want = oracle.exact_topk(q[:4], corpus, 10, mode=oracle.F64, fast=True)
+        assert_topk_matches(ids[:4], scores[:4], counts[:4], *want, tol=TOL)
+        # the next search on the same workspace starts clean
+        ids2, _, _ = ix.search(q[1:], 10)
+        assert np.array_equal(ids2, ids[1:])
+        assert ix.prefilter_stats()["searches"] == 1
+    finally:
+        ix.close()
+
+
+def test_candidate_statistics_stay_near_k(gpu, monkeypatch):
+    """Byte accounting behind bench.py's roofline: on the bench's corpus shape the filter passes a few dozen rows
+    per query and rescoring touches about k + a few of them."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    c = torch.randn(100_000, 1024, generator=g, device=dev)
+    c /= c.norm(dim=1, keepdim=True)
+    q = torch.randn(64, 1024, generator=g, device=dev)
+    monkeypatch.delenv("CRAG_NO_PREFILTER", raising=False)
+    with DenseIndex(1024, capacity=100_000) as ix:
+        ix.add(c)
+        for k, cand_max, resc_max in ((10, 400, 40), (50, 1200, 120), (100, 2500, 220)):
+            ix.prefilter_stats()
+            for _ in range(4):
+                ix.search(q, k)
+            s = ix.prefilter_stats()
+            per_query_c = s["candidates"] / s["searches"] / 64
+            per_query_r = s["rescored_rows"] / s["searches"] / 64
+            print(f"\nk={k}: candidates/query {per_query_c:.1f}, rescored rows/query {per_query_r:.1f}")
+            assert s["searches"] == 4 and k <= per_query_r <= resc_max and per_query_c <= cand_max
+
+
+def test_rows_with_extreme_norms_keep_the_index_on_the_fp32_scan(gpu, monkeypatch):
+    rng = np.random.default_rng(6)
+    corpus = unit_rows(rng, 40_000)
+    corpus[123] *= np.float32(1e-33)      # norm far below fp32's comfortable range: no proven fp16 bound
+    q = rng.standard_normal((8, 1024)).astype(np.float32)
+    ix = _index(corpus, monkeypatch)
+    try:
+        got = ix.search(q, 10)
+        assert "prefilter" not in ix.last_scan_kernel()
+        want = oracle.exact_topk(q, corpus, 10, mode=oracle.F64, fast=True)
+        assert_topk_matches(*got, *want, tol=TOL)
+    finally:
+        ix.close()
