@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — dense-lane benchmark (contract: see DESIGN.md "Measurement").
 
-A "step" is one pass of the hot path over one batch: QUERIES_PER_STEP fp32 query vectors
-(already resident in HBM) -> exact cosine top-K over this rank's 100k x 1024 fp32 corpus shard
-(BASELINE.json configs[1]) -> [N>1 only] RCCL all-gather of the per-shard top-k + on-GPU merge.
+A "step" is one pass of the hot path over one batch: QUERIES_PER_STEP fp32 query vectors (already resident in
+HBM) -> exact cosine top-K over this rank's fp32 corpus shard -> [N > 1 only] the path's one exchange step, an
+RCCL all-gather of the per-shard top-k + the on-GPU merge.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `value` counts the query-over-shard units all ranks processed per
-second (N=1: plain queries/sec over the 100k corpus); `config.distinct_queries_per_s` is the
-end-to-end rate of distinct queries answered over the whole N x 100k corpus.
+Workloads (BASELINE.json):
+  N = 1   configs[1]: 100 000 x 1024 corpus, 64 queries per step, top-10.  The same line carries `target_1m`
+          (1M x 1024 on one GPU, 32 and 64 queries per step: the north-star >= 70 % HBM target) and `encode`
+          (configs[3] shape).
+  N > 1   configs[2]: ONE 1M x 1024 corpus sharded over the N ranks (contiguous row shards), every rank searches
+          the same 64 queries, one all-gather, merge.  Total work is fixed: "scaling": "strong"; the 1-GPU point
+          of that curve is `target_1m.q64` of the N = 1 line.  `--mode weak` instead keeps 100 000 rows per rank.
+`value` is always DISTINCT queries answered per second by the whole job (never multiplied by the rank count).
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -25,57 +32,163 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-ROWS_PER_GPU = 100_000
+ROWS_CONFIG1 = 100_000
+ROWS_CONFIG2 = 1_000_000
 DIM = 1024
 TOPK = 10
-QUERIES_PER_STEP = 64   # one pass of the 64-query kernel (two 32-query MFMA blocks per corpus fragment)
+QUERIES_PER_STEP = 64
 FP32_MFMA_PEAK_TFS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0       # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+SYNTH_CHUNK = 125_000
+
+
+def synth_rows(lo: int, hi: int, seed: int, device) -> torch.Tensor:
+    """Rows [lo, hi) of the synthetic matrix of SURVEY.md 8(d): standard normal rows, L2-normalised, fixed seed.
+    The matrix is DEFINED in chunks of 125 000 rows, chunk i from the device generator seeded seed*1000 + i, so a
+    row's value does not depend on how many rows are asked for or on which rank generates it (a 1M x 1024
+    corpus is 4.1 GB: generated on the device, chunk by chunk)."""
+    out = torch.empty(hi - lo, DIM, dtype=torch.float32, device=device)
+    for ci in range(lo // SYNTH_CHUNK, (hi + SYNTH_CHUNK - 1) // SYNTH_CHUNK):
+        g = torch.Generator(device=device).manual_seed(seed * 1000 + ci)
+        blk = torch.randn(SYNTH_CHUNK, DIM, generator=g, device=device, dtype=torch.float32)
+        blk /= blk.norm(dim=1, keepdim=True)
+        a, b = max(lo, ci * SYNTH_CHUNK), min(hi, (ci + 1) * SYNTH_CHUNK)
+        out[a - lo:b - lo] = blk[a - ci * SYNTH_CHUNK:b - ci * SYNTH_CHUNK]
+        del blk
+    return out
 
 
 def synth(rows: int, seed: int, device) -> torch.Tensor:
-    """standard normal rows, L2-normalised, fixed seed."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    x = torch.randn(rows, DIM, generator=g, dtype=torch.float32)
-    x /= x.norm(dim=1, keepdim=True)
-    return x.to(device)
+    return synth_rows(0, rows, seed, device)
 
 
-def cpu_baseline(corpus_host: np.ndarray, queries_host: np.ndarray, gpu_ids: np.ndarray):
-    """Time the CPU restatement of the reference's exact scan (oracle/, kind "port") on a bounded
-    sample of the same workload, and use its result to check recall@10 of the GPU answer."""
+def timed_rounds(step, fence, steps: int, rounds: int):
+    """`rounds` repetitions of EXACTLY `steps` steps, each bracketed by fence() on both sides."""
+    times = []
+    for _ in range(rounds):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        times.append(time.perf_counter() - t0)
+    return times
+
+
+def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_extra=None, outs=None,
+               prewarm_s=0.3):
+    """Warm up, then time `rounds` x `steps` searches of `queries` (device tensor) on torch's current stream.
+    Returns timing + live HIP-event kernel times + the prefilter path's candidate statistics."""
+    dev = queries.device
+    nq = int(queries.shape[0])
+    if outs is None:
+        outs = (torch.empty(nq, k, dtype=torch.int64, device=dev), torch.empty(nq, k, dtype=torch.float32, device=dev),
+                torch.empty(nq, dtype=torch.int32, device=dev))
+    oi, osc, oc = outs
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        index.search_async(queries, k, oi, osc, oc, stream=stream)
+        if step_extra is not None:
+            step_extra()
+
+    def fence():
+        if fence_extra is not None:
+            fence_extra()
+        torch.cuda.synchronize()
+
+    t_end = time.perf_counter() + prewarm_s  # clocks ramp over ~0.1 s; untimed
+    while time.perf_counter() < t_end:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    fence()
+    index.prefilter_stats()
+    index.profile_enable(max(1, (steps * rounds) // 64))  # >= 64 event samples, on the launch stream
+    times = timed_rounds(step, fence, steps, rounds)
+    n_launch, scan_ms, rest_ms = index.profile_read()
+    index.profile_enable(0)
+    stats = index.prefilter_stats()
+    return {"times": times, "n_launch": n_launch, "scan_us": scan_ms / max(n_launch, 1) * 1e3,
+            "rest_us": rest_ms / max(n_launch, 1) * 1e3, "stats": stats, "kernel": index.last_scan_kernel(),
+            "out": (oi, osc, oc)}
+
+
+def roofline(rows, nq, k, leg, traffic_doc):
+    """algorithmic bytes = N*D*4 + Q*D*4 + Q*k*12 per launch, / the scan kernel's live event time."""
+    alg = rows * DIM * 4 + nq * DIM * 4 + nq * k * 12
+    scan_s = leg["scan_us"] * 1e-6
+    gbs = alg / scan_s / 1e9 if scan_s > 0 else 0.0
+    q_pad = ((nq + 31) // 32) * 32
+    per = max(leg["stats"]["searches"], 1)
+    prefilter = "prefilter" in leg["kernel"]
+    out = {
+        "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+        "kernel": leg["kernel"], "kernel_avg_us": round(leg["scan_us"], 2),
+        "other_kernels_avg_us": round(leg["rest_us"], 2), "launches_timed": leg["n_launch"],
+        "algorithmic_bytes_per_launch": alg,
+        "matrix_pipe": ("fp16 MFMA (v_mfma_f32_32x32x16_f16), %.1f TFLOP/s of the 2500 dense peak: not the bound"
+                        % (2.0 * q_pad * rows * DIM / scan_s / 1e12)) if prefilter else
+                       ("fp32 MFMA %.1f TFLOP/s = %.3f of %.1f" % (2.0 * q_pad * rows * DIM / scan_s / 1e12,
+                                                                    2.0 * q_pad * rows * DIM / scan_s / 1e12 / FP32_MFMA_PEAK_TFS,
+                                                                    FP32_MFMA_PEAK_TFS)),
+    }
+    if prefilter:  # declared separately (SURVEY 8(d)): rows re-read for the exact fp32 score, 4 KiB each
+        out["rescored_rows_per_launch"] = round(leg["stats"]["rescored_rows"] / per, 1)
+        out["rescored_bytes_per_launch"] = int(leg["stats"]["rescored_rows"] / per * DIM * 4)
+        out["candidates_per_launch"] = round(leg["stats"]["candidates"] / per, 1)
+    key = f"{rows}x{nq}x{k}"
+    if traffic_doc and key in traffic_doc.get("by_workload", {}):
+        t = traffic_doc["by_workload"][key]
+        if t.get("kernel", "").split("(")[0].replace("void ", "") == leg["kernel"]:
+            out["traffic"] = t["hbm_bytes_per_launch"]
+            out["traffic_source"] = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in " \
+                                    "separate earlier runs (FETCH x2 per the gfx950 note), not measured in this run"
+    return out
+
+
+def recall_check(corpus_host, queries_host, gpu_ids, k, sample):
+    """recall@10 (eval/run_eval.py:52-55) and order identity of the GPU answer vs the fp64 oracle on `sample`."""
     import oracle
+    oracle.set_threads(min(os.cpu_count() or 1, 64))
+    truth, _, _ = oracle.exact_topk(queries_host[sample], corpus_host, k, mode=oracle.F64, fast=True)
+    hits = sum(len(set(truth[i, :10].tolist()) & set(gpu_ids[s, :10].tolist())) for i, s in enumerate(sample))
+    return hits / float(len(sample) * min(k, 10)), bool(np.array_equal(truth, gpu_ids[sample]))
 
+
+def cpu_baseline(corpus_host: np.ndarray, queries_host: np.ndarray):
+    """The CPU restatement of the reference's exact scan (oracle/, kind "port") timed on a bounded sample of the
+    same workload on this box's host cores."""
+    import oracle
     cores = os.cpu_count() or 1
     oracle.set_threads(1)
     nq1 = 8
     t0 = time.perf_counter()
     oracle.exact_topk(queries_host[:nq1], corpus_host, TOPK, mode=oracle.F32SEQ, fast=True)
-    t1 = time.perf_counter() - t0
-    single = nq1 / t1
+    single = nq1 / (time.perf_counter() - t0)
     threads = min(cores, 64)
     oracle.set_threads(threads)
     nqa = min(len(queries_host), max(threads, 32))
     reps = 0
     t0 = time.perf_counter()
     while True:
-        ids_f32, _, _ = oracle.exact_topk(queries_host[:nqa], corpus_host, TOPK, mode=oracle.F32SEQ, fast=True)
+        oracle.exact_topk(queries_host[:nqa], corpus_host, TOPK, mode=oracle.F32SEQ, fast=True)
         reps += 1
         if time.perf_counter() - t0 > 6.0 or reps >= 20:
             break
-    ta = time.perf_counter() - t0
-    allc = reps * nqa / ta
-    # recall@10 vs the fp64 truth oracle (eval/run_eval.py:52-55 definition)
-    truth, _, _ = oracle.exact_topk(queries_host[:nqa], corpus_host, TOPK, mode=oracle.F64, fast=True)
-    hits = sum(len(set(truth[i].tolist()) & set(gpu_ids[i].tolist())) for i in range(nqa))
-    recall = hits / float(nqa * TOPK)
-    same_order = bool(np.array_equal(truth, gpu_ids[:nqa]))
+    allc = reps * nqa / (time.perf_counter() - t0)
     return {
         "value": round(allc, 2), "unit": "queries/sec", "cores": threads, "kind": "port",
         "sample": f"{nqa} queries x {reps} reps over the same {len(corpus_host)}x{DIM} corpus, "
                   f"top-{TOPK}; oracle/exact_scan.c built with pgvector's float flags + OpenMP",
         "single_core_value": round(single, 2),
-    }, recall, same_order
+    }
 
 
 def cpu_encode_baseline(n_chunks: int = 2, tokens: int = 256):
@@ -101,8 +214,7 @@ def cpu_encode_baseline(n_chunks: int = 2, tokens: int = 256):
                     prm.fill_(1.0)
                 else:
                     prm.uniform_(-0.02, 0.02)
-            # rotary tables are buffers: rebuild them after to_empty
-            for mod in model.modules():
+            for mod in model.modules():  # rotary tables are buffers: rebuild them after to_empty
                 if hasattr(mod, "inv_freq") and hasattr(mod, "original_inv_freq"):
                     inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32) / c.head_dim))
                     mod.inv_freq = inv
@@ -123,10 +235,12 @@ def cpu_encode_baseline(n_chunks: int = 2, tokens: int = 256):
 
 
 def encode_leg(dev, rank: int, world: int, dist, steps: int):
-    """chunks embedded/sec (second half of BASELINE.json's metric; configs[3] shape): batch = 256
-    synthetic chunks, lengths ~N(256, 96) clipped to [8, 1024] and rescaled to mean 256, packed (no
-    pad FLOPs), full Qwen3-Embedding-4B architecture with seeded random bf16 weights (no checkpoint
-    is reachable offline; throughput is value-independent).  Data-parallel replicas: no collective."""
+    """chunks embedded/sec (second half of BASELINE.json's metric; configs[3] shape): batch = 256 synthetic
+    chunks, lengths ~N(256, 96) clipped to [8, 1024] and rescaled to mean 256, packed (no pad FLOPs), full
+    Qwen3-Embedding-4B architecture with seeded random bf16 weights (no checkpoint is reachable offline;
+    throughput is value-independent).  Data-parallel replicas: no collective.  Two rates: `value` times
+    forward_packed on pre-tokenised device ids (the kernel-level rate); `backfill_path` drives the real
+    run_embedding_backfill loop (texts -> tokeniser -> packing -> forward -> store -> HBM index sink)."""
     from cadence_rag_amd.encoder.qwen3 import PackedBatch, Qwen3Config, Qwen3Encoder
 
     cfg = Qwen3Config()
@@ -137,7 +251,8 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int):
     lens = (lens * (256 * n_chunks / lens.sum())).round().astype(int).clip(8, 1024)
     batch = PackedBatch.build(lens, dev)
     ids = torch.from_numpy(rng.integers(0, cfg.vocab_size, size=int(lens.sum())).astype(np.int32)).to(dev)
-    enc.forward_packed(ids, batch)  # warmup (GEMM autotune, allocator)
+    for _ in range(2):
+        enc.forward_packed(ids, batch)  # warmup (GEMM autotune, allocator)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -156,9 +271,7 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int):
     ctx = float((lens.astype(float) ** 2).sum() / lens.sum())
     tflops = cfg.flops_per_token(ctx) * tokens * steps / dt / 1e12
     ok = bool(torch.isfinite(out).all().item()) and bool(torch.allclose(out.norm(dim=1), torch.ones(n_chunks, device=dev), atol=1e-3))
-    del enc
-    torch.cuda.empty_cache()
-    return {
+    res = {
         "metric": "chunks embedded/sec", "value": round(world * n_chunks * steps / dt, 2), "unit": "chunks/sec",
         "tokens_per_s": round(world * tokens * steps / dt, 1), "ms_per_batch": round(dt / steps * 1e3, 2),
         "steps": steps, "batch_chunks": n_chunks, "avg_tokens": round(tokens / n_chunks, 1), "dtype": "bf16",
@@ -170,22 +283,74 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int):
                      "frac": round(tflops / 2500.0, 4), "traffic": None,
                      "note": "per GPU; whole forward (library GEMMs + HIP ops), algorithmic FLOPs 2*P + causal attention"},
     }
+    if rank == 0:
+        try:
+            res["backfill_path"] = backfill_path_leg(enc, cfg, dev)
+        except Exception as exc:  # the kernel-level rate above must still be reported
+            res["backfill_path"] = {"error": f"{type(exc).__name__}: {exc}"}
+    del enc
+    torch.cuda.empty_cache()
+    return res
+
+
+def backfill_path_leg(enc, cfg, dev, n_rows: int = 1536, batch_size: int = 256):
+    """run_embedding_backfill end to end (reference entry point embedding_pipeline.py:241) over synthetic texts of
+    ~256 tokens: fetch -> tokenise -> pack -> forward -> store -> DenseIndex sink in HBM, in the two forms the
+    store can take the vectors in: host lists (the reference's List[List[float]] contract) and device-resident."""
+    from uuid import UUID
+    from cadence_rag_amd import embedding_pipeline as ep, embeddings
+    from cadence_rag_amd.config import settings
+    from cadence_rag_amd.dense_index import DenseIndex
+    from cadence_rag_amd.encoder.qwen3 import ByteTokenizer
+    enc.tokenizer = ByteTokenizer(eos_id=256)
+    rng = np.random.default_rng(99)
+    lens = np.clip(rng.normal(255, 96, size=n_rows).round().astype(int), 8, 1000)
+    alphabet = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz      ", dtype=np.uint8)
+    texts = ["x" + bytes(alphabet[rng.integers(0, len(alphabet), size=n - 1)]).decode() for n in lens]
+    old = (settings.embeddings_base_url, settings.embeddings_dim)
+    settings.embeddings_base_url, settings.embeddings_dim = "native", cfg.out_dim
+    embeddings.set_encoder(enc)
+    out = {"rows": n_rows, "batch_size": batch_size, "avg_tokens": round(float(lens.mean()) + 1, 1),
+           "tokenizer": "ByteTokenizer stand-in (utf-8 bytes; no Qwen tokenizer files offline)"}
+    try:
+        for mode in ("host_lists", "device_resident"):
+            tables = {"chunks": {i: {"call_id": UUID(int=1 + i % 7), "text": texts[i], "embedding": None}
+                                 for i in range(n_rows)}, "artifact_chunks": {}}
+            with DenseIndex(cfg.out_dim, capacity=n_rows) as sink:
+                store_cls = ep.InMemoryStore if mode == "host_lists" else ep.DeviceSinkStore
+                ep.set_store(store_cls(tables, sinks={"chunks": sink}))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                summary = ep.run_embedding_backfill(batch_size=batch_size)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                assert summary.rows_updated == n_rows and len(sink) == n_rows
+            out[mode] = {"chunks_per_s": round(n_rows / dt, 1), "seconds": round(dt, 3)}
+    finally:
+        ep.set_store(None)
+        embeddings.set_encoder(None)
+        settings.embeddings_base_url, settings.embeddings_dim = old
+    return out
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows-per-gpu", type=int, default=ROWS_PER_GPU)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--rounds", type=int, default=5,
+                    help="the K timed steps are repeated this many times; `value` comes from the FIRST round "
+                         "(exactly K steps, the contract), median and min over the rounds are reported beside it")
+    ap.add_argument("--rows-per-gpu", type=int, default=0, help="override the corpus rows held by each rank")
+    ap.add_argument("--mode", choices=("auto", "strong", "weak"), default="auto",
+                    help="N > 1: strong = one 1M-row corpus sharded over the ranks (BASELINE configs[2], default); "
+                         "weak = 100 000 rows per rank")
     ap.add_argument("--queries", type=int, default=QUERIES_PER_STEP)
     ap.add_argument("--topk", type=int, default=TOPK)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="issue consecutive steps round-robin on this many HIP streams (independent query "
-                         "batches may overlap on the GPU); 1 = strictly one step after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
-    ap.add_argument("--encode-steps", type=int, default=3)
+    ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
+    ap.add_argument("--encode-steps", type=int, default=20)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,124 +378,149 @@ def main() -> None:
             dist.init_process_group(backend)
 
     from cadence_rag_amd.dense_index import DenseIndex, ResultRecord, merge_topk_packed
+    from cadence_rag_amd.sharded import shard_bounds
 
-    rows, nq, k = args.rows_per_gpu, args.queries, args.topk
-    corpus = synth(rows, 1234 + rank, dev)
+    nq, k = args.queries, args.topk
+    mode = args.mode if args.mode != "auto" else ("strong" if world > 1 else "single")
+    if world == 1:
+        rows_total = args.rows_per_gpu or ROWS_CONFIG1
+        lo, hi = 0, rows_total
+        workload = f"BASELINE configs[1]: brute-force cosine top-{k}, {rows_total}x{DIM} fp32 corpus on one GPU, " \
+                   f"{nq} queries/step resident in HBM"
+    elif mode == "strong":
+        rows_total = (args.rows_per_gpu * world) if args.rows_per_gpu else ROWS_CONFIG2
+        lo, hi = shard_bounds(rows_total, world, rank)
+        workload = f"BASELINE configs[2]: ONE {rows_total}x{DIM} fp32 corpus in {world} contiguous row shards, " \
+                   f"{nq} queries/step, per-shard top-{k} + one RCCL all-gather + merge"
+    else:
+        per = args.rows_per_gpu or ROWS_CONFIG1
+        rows_total = per * world
+        lo, hi = rank * per, (rank + 1) * per
+        workload = f"weak mode: {per}x{DIM} rows per rank ({rows_total} in all), {nq} queries/step, per-shard " \
+                   f"top-{k} + one RCCL all-gather + merge"
+    rows = hi - lo
+    corpus = synth_rows(lo, hi, 1234, dev)  # this rank's rows of the one global corpus
     queries = synth(max(nq, 64), 4321, dev)[:nq].contiguous()  # same queries on every rank
-    ids = torch.arange(rank * rows, (rank + 1) * rows, dtype=torch.int64, device=dev)
+    ids = torch.arange(lo, hi, dtype=torch.int64, device=dev)
     index = DenseIndex(DIM, capacity=rows, device=dev_index)
     index.add(corpus, ids)
 
-    rec = ResultRecord(nq, k, dev)  # the search writes straight into the record that gets all-gathered
-    out_ids, out_sc, out_ct = rec.ids, rec.scores, rec.counts
+    step_extra = fence_extra = outs = None
     if world > 1:
+        rec = ResultRecord(nq, k, dev)  # the search writes straight into the record that gets all-gathered
+        outs = (rec.ids, rec.scores, rec.counts)
         gathered = torch.empty(world * rec.nbytes, dtype=torch.uint8, device=dev)
-        f_ids = torch.empty_like(out_ids)
-        f_sc = torch.empty_like(out_sc)
-        f_ct = torch.empty_like(out_ct)
+        f_ids = torch.empty(nq, k, dtype=torch.int64, device=dev)
+        f_sc = torch.empty(nq, k, dtype=torch.float32, device=dev)
+        f_ct = torch.empty(nq, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
 
-    stream = torch.cuda.current_stream().cuda_stream
-    extra_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1) - 1)] if world == 1 else []
-    lanes = [(stream, out_ids, out_sc, out_ct)] + [
-        (s.cuda_stream, torch.empty(nq, k, dtype=torch.int64, device=dev),
-         torch.empty(nq, k, dtype=torch.float32, device=dev), torch.empty(nq, dtype=torch.int32, device=dev))
-        for s in extra_streams]
-    counter = [0]
-
-    def step() -> None:
-        if len(lanes) > 1:  # independent batches, round-robin over the streams
-            st_, oi_, os_, oc_ = lanes[counter[0] % len(lanes)]
-            counter[0] += 1
-            index.search_async(queries, k, oi_, os_, oc_, stream=st_)
-            return
-        index.search_async(queries, k, out_ids, out_sc, out_ct, stream=stream)
-        if world > 1:  # the path's one exchange step: ONE all-gather of 12*Q*k + 4*Q bytes per rank over xGMI
+        def step_extra():  # the path's one exchange step: ONE all-gather of 12*Q*k + 4*Q bytes per rank over xGMI,
+            # then the merge; everything is enqueued, nothing synchronises with the host
             dist.all_gather_into_tensor(gathered, rec.buf)
             merge_topk_packed(gathered, world, nq, k, f_ids, f_sc, f_ct, stream=stream)
 
-    def fence() -> None:
-        if world > 1:
+        def fence_extra():
             dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    index.profile_enable(8)  # HIP events around every 8th scan launch of the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    n_launch, scan_ms, merge_ms = index.profile_read()
-    index.profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    leg = search_leg(index, queries, k, args.steps, args.warmup, args.rounds, step_extra, fence_extra, outs)
+    times = leg["times"]
+    if world > 1:  # max over ranks, per round
+        t = torch.tensor(times, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        times = t.tolist()
+    elapsed = times[0]
+
+    traffic_doc = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic_doc = json.load(open(tpath))
+        except Exception:
+            traffic_doc = None
+
+    target = None
+    if world == 1 and not args.no_target_1m and rows_total == ROWS_CONFIG1:
+        gpu_ids_100k = leg["out"][0].cpu().numpy()
+        corpus_host_100k = corpus.cpu().numpy()
+        index.close()
+        del corpus, index
+        torch.cuda.empty_cache()
+        big = synth(ROWS_CONFIG2, 1234, dev)
+        big_index = DenseIndex(DIM, capacity=ROWS_CONFIG2, device=dev_index)
+        big_index.add(big)
+        target = {"workload": f"north-star target: {ROWS_CONFIG2}x{DIM} fp32 corpus on ONE GPU, exact top-{k}, "
+                              "queries resident in HBM"}
+        q64 = synth(64, 4321, dev)
+        big_host = None
+        for name, qn, st_ in (("q32", 32, 300), ("q64", 64, 300)):
+            tl = search_leg(big_index, q64[:qn].contiguous(), k, st_, 20, 3)
+            if big_host is None and not args.no_cpu_baseline:
+                big_host = big.cpu().numpy()
+            entry = {"queries_per_step": qn, "steps": st_, "rounds": 3,
+                     "ms_per_step": round(tl["times"][0] / st_ * 1e3, 5),
+                     "ms_per_step_median": round(statistics.median(tl["times"]) / st_ * 1e3, 5),
+                     "value": round(qn * st_ / tl["times"][0], 2), "unit": "queries/sec",
+                     "roofline": roofline(ROWS_CONFIG2, qn, k, tl, traffic_doc)}
+            if big_host is not None:
+                sample = [0, qn // 2, qn - 1]
+                rc, same = recall_check(big_host, q64.cpu().numpy(), tl["out"][0].cpu().numpy(), k, sample)
+                entry["recall_at_10_vs_fp64_oracle"] = rc
+                entry["topk_order_identical_to_oracle"] = same
+                entry["oracle_sample"] = f"queries {sample} of the step's batch, full {ROWS_CONFIG2}-row fp64 scan each"
+            target[name] = entry
+        big_index.close()
+        del big, big_index
+        torch.cuda.empty_cache()
+    else:
+        gpu_ids_100k = leg["out"][0].cpu().numpy() if world == 1 else None
+        corpus_host_100k = corpus.cpu().numpy() if (world == 1 and not args.no_cpu_baseline) else None
+        index.close()
 
     encode = None
     if not args.no_encode:
         encode = encode_leg(dev, rank, world, dist, args.encode_steps)
 
     if rank == 0:
-        geo = index.scan_geometry(nq)
-        scan_avg_s = scan_ms / max(n_launch, 1) / 1e3
-        achieved = geo["algorithmic_bytes"] / scan_avg_s / 1e9 if scan_avg_s > 0 else 0.0
-        # fp32 MFMA work of one launch: 2*Q*N*D with Q rounded up to whole 32-query MFMA blocks
-        q_pad = ((nq + 31) // 32) * 32
-        flops = 2.0 * q_pad * rows * DIM
-        tflops = flops / scan_avg_s / 1e12 if scan_avg_s > 0 else 0.0
-        # > 32 queries per pass: intensity Q/2 = 32 flop/B is past the 19.7 flop/B ridge -> matrix-pipe bound
-        mfma_bound = nq > 32  # 64 queries per pass: intensity 32 flop/B, above the fp32-MFMA ridge
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-        if os.path.exists(tpath) and rows == ROWS_PER_GPU and k == TOPK:
-            try:  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/traffic.json says how)
-                traffic = json.load(open(tpath))["by_queries_per_step"][str(nq)]["scan_kernel_hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        roof = roofline(rows, nq, k, leg, traffic_doc)
         line = {
             "metric": "queries/sec @ recall@10=1.0 (exact cosine top-10, 1024-d fp32 corpus)",
-            "value": round(world * nq * args.steps / elapsed, 2),
+            "value": round(nq * args.steps / elapsed, 2),
             "unit": "queries/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True,
+            "scaling": "strong" if mode == "strong" else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: brute-force cosine top-{k}, {rows}x{DIM} fp32 corpus "
-                            f"per GPU, {nq} queries/step resident in HBM",
-                "rows_per_gpu": rows, "rows_total": rows * world, "dim": DIM, "k": k,
-                "queries_per_step": nq, "streams": len(lanes),
+                "workload": workload,
+                "rows_per_gpu": rows, "rows_total": rows_total, "dim": DIM, "k": k, "queries_per_step": nq,
                 "parallelism": "1 GPU" if world == 1 else f"corpus sharded x{world}, all-gather top-k merge",
-                "distinct_queries_per_s": round(nq * args.steps / elapsed, 2),
-                "encode": "not included in this step (encoder lane reported separately when built)",
+                "value_counts": "distinct queries answered per second by the whole job (not multiplied by ranks)",
+                "rounds": args.rounds,
+                "ms_per_step_rounds": [round(t / args.steps * 1e3, 5) for t in times],
+                "ms_per_step_median": round(statistics.median(times) / args.steps * 1e3, 5),
+                "ms_per_step_min": round(min(times) / args.steps * 1e3, 5),
+                "row_queries_per_s": round(rows_total * nq * args.steps / elapsed, 1),
+                "arithmetic": "fp16 MFMA prefilter with a proven error bound + exact fp32 rescoring of the "
+                              "survivors: results bit-identical to the fp32 scan (DESIGN.md 4)",
             },
-            "roofline": ({
-                "bound": "mfma", "achieved": round(tflops, 1), "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": round(tflops / FP32_MFMA_PEAK_TFS, 4), "traffic": traffic,
-                "kernel": f"crag::scan_pipe2_kernel<{1 if k <= 32 else (2 if k <= 64 else 4)}, 2>", "kernel_avg_us": round(scan_avg_s * 1e6, 2),
-                "hbm_achieved_gbs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
-            } if mfma_bound else {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "crag::scan_pipe_kernel" if k <= 32 else f"crag::scan_pipe2_kernel<{2 if k <= 64 else 4}, 1>",
-                "kernel_avg_us": round(scan_avg_s * 1e6, 2),
-                "mfma_tflops": round(tflops, 1), "mfma_frac": round(tflops / FP32_MFMA_PEAK_TFS, 4),
-            }) | {
-                "merge_avg_us": round(merge_ms / max(n_launch, 1) * 1e3, 2),
-                "algorithmic_bytes_per_launch": geo["algorithmic_bytes"],
-                "workgroups": geo["workgroups"], "launches_timed": n_launch,
-            },
+            "roofline": roof,
         }
+        if world > 1:
+            line["config"]["scaling_reference"] = (
+                "strong scaling of the fixed 1M-row job: the 1-GPU point is `target_1m.q64.value` of the N = 1 line "
+                "(the N = 1 `value` is configs[1], a 100 000-row corpus)" if mode == "strong" else
+                "weak scaling: the corpus grows with N, so a flat `value` is ideal; compare `row_queries_per_s`")
+        if target is not None:
+            line["target_1m"] = target
         if encode is not None:
             line["encode"] = encode
-            line["config"]["encode"] = "see top-level 'encode' (chunks embedded/sec, BASELINE configs[3] shape)"
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (rank 0's host cores)
-            # rank 0's own shard result (before the cross-shard merge) vs the oracle on that shard
-            base, recall, same_order = cpu_baseline(corpus.cpu().numpy(), queries.cpu().numpy(),
-                                                    out_ids.cpu().numpy())
+            queries_host = queries.cpu().numpy()
+            base = cpu_baseline(corpus_host_100k, queries_host)
+            sample = list(range(0, nq, max(1, nq // 16)))
+            recall, same_order = recall_check(corpus_host_100k, queries_host, gpu_ids_100k, k, sample)
             if encode is not None:
                 base["encode"] = cpu_encode_baseline()
             line["cpu_baseline"] = base
@@ -341,7 +531,6 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    index.close()
 
 
 if __name__ == "__main__":

@@ -234,8 +234,8 @@ def test_full_forward_matches_transformers_qwen3(gpu, pooling):
     cos = (got * want).sum(-1)
     assert torch.allclose(got.norm(dim=1), torch.ones(len(token_lists)), atol=1e-4)
     # bf16 pipeline vs fp32 oracle, per element of a unit-norm 64-d output (typical magnitude 1/8): ~36 bf16
-    # roundings (3 layers x 12) of rms 1.1e-3 relative each add to sqrt(36) * 1.1e-3 = 0.7 % = 8e-4 rms;
-    # the weights here have std 0.05 (activations grow through the layers), head room 3x
+    # roundings (3 layers x 12) of rms 2^-8/sqrt(3) = 2.3e-3 relative each add to sqrt(36) * 2.3e-3 = 1.4 % =
+    # 1.7e-3 rms; measured on MI355X 1.35e-3 rms / 4.3e-3 max (last), 6.8e-4 / 2.4e-3 (mean); bars ~2x measured
     diff = (got - want).abs()
     print(f"\ntoy forward ({pooling}): max |d| = {diff.max():.2e}, rms = {diff.pow(2).mean().sqrt():.2e}, "
           f"min cos = {cos.min():.6f}")
@@ -329,12 +329,13 @@ def _real_width_hf_and_mine(layers=2, vocab=2048):
 def test_real_width_layers_match_transformers_qwen3(gpu):
     """Two decoder layers at the exact 4B widths, ragged lengths incl. 1 / 33 / 257 / 1024, packed HIP forward
     vs transformers' Qwen3Model in fp32 on the CPU.  Tolerance, per element of the unit-norm 1024-d output
-    (typical magnitude 1/32 = 3.1e-2): the HIP path keeps activations in bf16 (8 significant bits, relative
-    rounding error <= 2^-9, rms 2^-9/sqrt(3) = 1.1e-3) and rounds ~12 times per layer (norm out, qkv, rope,
-    P, attention out, o-proj, two residuals, norm, gate|up, SwiGLU, down); independent roundings add in
-    quadrature: sqrt(24) * 1.1e-3 = 0.55 % of an element's magnitude = 1.7e-4 rms, and over 8 x 1024
-    outputs the largest of them is ~4.5 sigma = 8e-4.  Bars: rms <= 4e-4, max <= 2e-3 (2.3x / 2.5x head
-    room for the attention softmax's bf16 P and the GEMMs' accumulation order), cosine >= 0.9999."""
+    (typical magnitude 1/32 = 3.1e-2): the HIP path keeps activations in bf16 — 8 significant bits, unit
+    roundoff 2^-8, rms relative rounding error 2^-8/sqrt(3) = 2.3e-3 — and rounds ~12 times per layer (norm
+    out, qkv, rope, P, attention out, o-proj, two residual sums, norm, gate|up, SwiGLU, down).  Independent
+    roundings add in quadrature: sqrt(24) * 2.3e-3 = 1.1 % of an element's magnitude = 3.5e-4 rms; over
+    8 x 1024 outputs the largest is ~4.5 sigma = 1.6e-3.  Measured on MI355X: rms 4.2e-4, max 1.9e-3, min
+    cosine 0.99988 (1 - 1024 * rms^2 / 2 = 0.99991).  Bars = 1.5x the measured values: rms <= 6.5e-4,
+    max <= 3e-3, cosine >= 0.9998."""
     model, enc, cfg = _real_width_hf_and_mine()
     rng = np.random.default_rng(11)
     lens = (1, 33, 257, 1024, 8, 64, 300, 31)
@@ -346,9 +347,11 @@ def test_real_width_layers_match_transformers_qwen3(gpu):
     print(f"\nreal-width 2-layer forward vs transformers fp32: max |d| = {diff.max():.2e}, "
           f"rms = {diff.pow(2).mean().sqrt():.2e}, min cos = {cos.min():.6f}")
     assert torch.allclose(got.norm(dim=1), torch.ones(len(lens)), atol=1e-5)
-    assert diff.pow(2).mean().sqrt() <= 4e-4
-    assert diff.max() <= 2e-3
-    assert cos.min() >= 0.9999
+    per_seq = diff.pow(2).mean(dim=1).sqrt()
+    print("  per sequence (len: rms): " + ", ".join(f"{n}: {v:.1e}" for n, v in zip(lens, per_seq.tolist())))
+    assert diff.pow(2).mean().sqrt() <= 6.5e-4
+    assert diff.max() <= 3e-3
+    assert cos.min() >= 0.9998
 
 
 def test_backfill_through_native_encoder_into_hbm_index(gpu, monkeypatch):
