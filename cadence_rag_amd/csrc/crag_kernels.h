@@ -60,6 +60,7 @@ struct PrepParams {
     float *a32;               // [nq_pad/32][8 waves][16][64] float4: raw queries in fp32 A-fragment order
     _Float16 *a16;            // nullable; [nq_pad/32][8 waves][8][64][8]: unit queries in fp16 A-fragment order
     uint32_t *pf_gbound;      // nullable; [nq_pad][PF_BOUND_CELLS], zeroed here
+    uint32_t *pf_tau;         // [nq_pad] best bound on the k-th best approximate score, zeroed here
     uint32_t *pf_count;       // [nq_pad] candidates per query, zeroed here
     uint32_t *pf_flags;       // [4]: [0] = a candidate list overflowed, zeroed here
 };
@@ -71,7 +72,8 @@ struct PfParams {
     const float *qinv;
     const uint32_t *mask;
     int64_t mask_stride_w;
-    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS]
+    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS] class maxima (orderable scores, atomic max)
+    uint32_t *tau;            // [nq_pad] shared bound per query (orderable score, atomic max)
     uint2 *cand;              // [nq_pad][cap]: x = orderable approximate score, y = row position
     uint32_t *count;          // [nq_pad]
     uint32_t *flags;

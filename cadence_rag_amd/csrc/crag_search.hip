@@ -1534,7 +1534,10 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(PrepParams p) {
     }
     if (p.pf_gbound) {
         if (t < PF_MAX_SETS * 32) p.pf_gbound[(size_t)q * (PF_MAX_SETS * 32) + t] = 0u;
-        if (t == 0) p.pf_count[q] = 0u;
+        if (t == 0) {
+            p.pf_count[q] = 0u;
+            p.pf_tau[q] = 0u;
+        }
         if (q == 0 && t < 4) p.pf_flags[t] = 0u;
     }
 }
@@ -1674,7 +1677,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
 
-    // class maxima of the owned queries, device-coherent loads (they are updated by every workgroup)
+    // Bounds.  p.tau[q] (orderable score, monotone, atomic max) is the best lower bound on the k-th best
+    // approximate score of query q any wave has derived so far; every tile reads it (one word per owned query).
+    // A wave DERIVES bounds only on its refresh tiles (the first two, then every REFRESH-th, staggered over the
+    // workgroups so that some workgroup refreshes on every tile): it loads the class maxima of its queries,
+    // takes per set the (k_s)-th largest of the 32 (half-wave sort) and the minimum over the sets.
+    constexpr int REFRESH = 4 * SETS;
+    uint32_t *const tau_ptr = p.tau + o.qg0;
+    auto load_tau = [&](uint32_t (&tau)[RPO]) {
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            tau[e] = ((o.okmask >> e) & 1u) ? __hip_atomic_load(tau_ptr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    };
     auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
@@ -1684,19 +1698,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                                ? __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                : 0u;
     };
-    // candidate thresholds of the owned queries: min over the sets of the (k_s)-th largest class maximum, - 2 delta
-    auto thresholds = [&](const uint32_t (&gb)[RPO][SETS], float (&thr)[RPO]) {
+    auto derive = [&](const uint32_t (&gb)[RPO][SETS], uint32_t (&tau)[RPO]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
-            uint32_t tau = 0xffffffffu;
+            uint32_t t = 0xffffffffu;
 #pragma unroll
             for (int s = 0; s < SETS; ++s) {
                 const uint32_t sorted = sort32_desc_u32(gb[e][s], lane);
                 const int ks = k_base + (s < k_rem ? 1 : 0);
                 const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
-                tau = kth < tau ? kth : tau;
+                t = kth < t ? kth : t;
             }
-            thr[e] = tau == 0u ? -__builtin_inff() : ord2f(tau) - 2.f * PF_DELTA;
+            if (t > tau[e]) {  // uniform over the half-wave
+                tau[e] = t;
+                if (j == 0) (void)__hip_atomic_fetch_max(tau_ptr + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     };
 
@@ -1709,12 +1725,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         // front of the next tile's, so they have arrived when the MFMA phase ends
         float inv_nxt = 0.f;
         if (ti + 1 < c.n_tiles) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1)) * 32 + j];
-        uint32_t mword[RPO], gb[RPO][SETS];
+        uint32_t mword[RPO], tau[RPO], gb[RPO][SETS];
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
             mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
                               : 0xffffffffu;
-        load_bounds(gb);
+        load_tau(tau);
+        const bool refresh = (ti < 2) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
+        if (refresh) load_bounds(gb);
 
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
@@ -1754,7 +1772,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) sc[e] += v[e];
         }
         buf ^= 1;
-        thresholds(gb, thr);
+        if (refresh) derive(gb, tau);
         const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
         const int set = (int)(tile & (int64_t)(SETS - 1));
         bool pass[RPO];
@@ -1762,13 +1780,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         for (int e = 0; e < RPO; ++e) {
             const bool ok = row_ok && ((o.okmask >> e) & 1u) && ((mword[e] >> j) & 1u) && (sc[e] == sc[e]);
             sc[e] = ok ? sc[e] : __uint_as_float(0x7fc00000u);
-            // publish an improved class maximum (rare: only a row that beats everything seen in its class)
-            uint32_t seen = gb[e][0];
-#pragma unroll
-            for (int s = 1; s < SETS; ++s) seen = (s == set) ? gb[e][s] : seen;
-            if (ok && f2ord(sc[e]) > seen)
-                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, f2ord(sc[e]), __ATOMIC_RELAXED,
+            const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
+            // Class maxima: only a row above the current bound can lift the k-th largest class maximum, so only
+            // such rows (the candidates, a few dozen per query and search) are published.  While no bound exists
+            // everything qualifies: then one workgroup in eight publishes a class, which fills every class
+            // 32 times over instead of 256 (an atomic storm on 32 cells per query otherwise).
+            const bool lift = tau[e] != 0u ? (ord > tau[e]) : (ord != 0u && (((c.g + j) & 7) == 0));
+            if (lift)
+                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
+            thr[e] = tau[e] == 0u ? -__builtin_inff() : ord2f(tau[e]) - 2.f * PF_DELTA;
             pass[e] = sc[e] >= thr[e];
         }
         if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
@@ -1782,13 +1803,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     }
     if (c.n_tiles > 0) {  // the first tile against the final bounds
         if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        uint32_t gb[RPO][SETS];
-        float thr[RPO];
+        uint32_t gb[RPO][SETS], tau[RPO];
+        load_tau(tau);
         load_bounds(gb);
-        thresholds(gb, thr);
+        derive(gb, tau);
         bool pass[RPO];
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
+        for (int e = 0; e < RPO; ++e)
+            pass[e] = stash[e] >= (tau[e] == 0u ? -__builtin_inff() : ord2f(tau[e]) - 2.f * PF_DELTA);
         pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
     }
     pf_flush<NQB>(p, L, c.t_begin * 32);
@@ -1824,9 +1846,12 @@ __device__ __forceinline__ float exact_slice_dot(const f32x4 *afrag /* + sub*16*
 
 __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     __shared__ uint64_t best[FIN_BEST];
+    __shared__ uint2 lcand[FIN_ROUND];     // the candidates of the common case (all of them fit): x = score, y = row
+    __shared__ uint32_t surv[FIN_ROUND];   // rows to rescore in the current round
     __shared__ int hist[256];
     __shared__ int wave_tot[MERGE_THREADS / 64];
-    __shared__ int s_digit, s_need, s_nbest, s_rescored;
+    __shared__ int s_digit, s_need, s_nbest, s_nsurv, s_rescored;
+    __shared__ uint32_t s_kth;
     const int q = blockIdx.x, tid = threadIdx.x;
     if (p.flags[0] != 0u) {  // uniform over the grid
         merge_partials_body(p.merge, q);
@@ -1835,63 +1860,84 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     const int k = p.k;
     const uint32_t total = p.count[q];
     const int C = (int)(total < (uint32_t)p.cap ? total : (uint32_t)p.cap);
-    const uint2 *cand = p.cand + (size_t)q * p.cap;
-
-    // 1. k-th largest approximate score (radix select over the 32-bit orderable scores, 4 x 8 bits)
-    uint32_t thr_ord = 0u;
-    if (C > k) {
-        uint32_t prefix = 0u, pmask = 0u;
-        int need = k;
-        for (int pass = 0; pass < 4; ++pass) {
-            const int shift = 24 - 8 * pass;
-            hist[tid] = 0;
-            __syncthreads();
-            for (int e = tid; e < C; e += MERGE_THREADS) {
-                const uint32_t o = cand[e].x;
-                if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1);
-            }
-            __syncthreads();
-            {
-                const int above = suffix_above(hist, wave_tot, tid);
-                const int here = hist[tid];
-                if (above < need && above + here >= need) {
-                    s_digit = tid;
-                    s_need = need - above;
-                }
-            }
-            __syncthreads();
-            prefix |= (uint32_t)s_digit << shift;
-            pmask |= 255u << shift;
-            need = s_need;
-            __syncthreads();
-        }
-        const float kth = ord2f(prefix);
-        thr_ord = f2ord(kth - 2.f * PF_DELTA);
-    }
+    const uint2 *gcand = p.cand + (size_t)q * p.cap;
+    const bool in_lds = C <= FIN_ROUND;
+    if (in_lds)
+        for (int e = tid; e < C; e += MERGE_THREADS) lcand[e] = gcand[e];
     if (tid == 0) {
         s_nbest = 0;
         s_rescored = 0;
+        s_kth = 0u;
     }
     __syncthreads();
 
-    // 2. exact rescoring, 8 lanes per candidate, in rounds of FIN_ROUND candidates
-    const int grp = tid >> 3, sub = tid & 7;  // 32 candidates per sweep; lane `sub` = K slice (the scan's wave w)
+    // 1. k-th largest approximate score among the candidates
+    uint32_t thr_ord = 0u;
+    if (C > k) {
+        if (C <= 2 * MERGE_THREADS) {  // the usual case (a few dozen candidates): rank by counting, one barrier
+            for (int e = tid; e < C; e += MERGE_THREADS) {
+                const uint32_t mine = lcand[e].x;
+                int rank = 0;
+                for (int i = 0; i < C; ++i) {
+                    const uint32_t o = lcand[i].x;
+                    rank += (o > mine || (o == mine && i < e)) ? 1 : 0;
+                }
+                if (rank == k - 1) s_kth = mine;
+            }
+            __syncthreads();
+        } else {  // radix select over the 32-bit orderable scores, 4 x 8 bits
+            uint32_t prefix = 0u, pmask = 0u;
+            int need = k;
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                hist[tid] = 0;
+                __syncthreads();
+                for (int e = tid; e < C; e += MERGE_THREADS) {
+                    const uint32_t o = in_lds ? lcand[e].x : gcand[e].x;
+                    if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1);
+                }
+                __syncthreads();
+                {
+                    const int above = suffix_above(hist, wave_tot, tid);
+                    const int here = hist[tid];
+                    if (above < need && above + here >= need) {
+                        s_digit = tid;
+                        s_need = need - above;
+                    }
+                }
+                __syncthreads();
+                prefix |= (uint32_t)s_digit << shift;
+                pmask |= 255u << shift;
+                need = s_need;
+                __syncthreads();
+            }
+            if (tid == 0) s_kth = prefix;
+            __syncthreads();
+        }
+        thr_ord = f2ord(ord2f(s_kth) - 2.f * PF_DELTA);
+    }
+
+    // 2. survivors -> exact scores, 8 lanes per row, in rounds of FIN_ROUND candidates
+    const int grp = tid >> 3, sub = tid & 7;  // 32 rows per sweep; lane `sub` = K slice (the scan's wave w)
     const int qb = q >> 5, qi = q & 31;
     const float qinv = p.qinv[q];
+    const f32x4 *afrag = reinterpret_cast<const f32x4 *>(p.a32) + ((size_t)(qb * SCAN_WAVES + sub) * 16) * 64 + qi;
     for (int r0 = 0; r0 < C; r0 += FIN_ROUND) {
         const int rn = (C - r0) < FIN_ROUND ? (C - r0) : FIN_ROUND;
-        for (int e0 = 0; e0 < rn; e0 += 32) {
+        if (tid == 0) s_nsurv = 0;
+        __syncthreads();
+        for (int e = tid; e < rn; e += MERGE_THREADS) {
+            const uint2 ce = in_lds ? lcand[e] : gcand[r0 + e];
+            if (ce.x >= thr_ord) surv[atomicAdd(&s_nsurv, 1)] = ce.y;
+        }
+        __syncthreads();
+        const int ns = s_nsurv;
+        for (int e0 = 0; e0 < ns; e0 += 32) {
             const int e = e0 + grp;
-            bool live = false;
-            uint32_t row = 0u;
-            if (e < rn) {
-                const uint2 ce = cand[r0 + e];
-                live = ce.x >= thr_ord;
-                row = ce.y;
-            }
+            const bool live = e < ns;
+            const uint32_t row = live ? surv[e] : 0u;
             float part = 0.f;
             if (live) {
-                const f32x4 *afrag = reinterpret_cast<const f32x4 *>(p.a32) + ((size_t)(qb * SCAN_WAVES + sub) * 16) * 64 + qi;
                 const f32x4 *ctile = reinterpret_cast<const f32x4 *>(p.corpus + (size_t)(row >> 5) * TILE_FLOATS) + (size_t)sub * 32 * 32;
                 part = exact_slice_dot(afrag, ctile, (int)(row & 31u));
             }
@@ -1900,20 +1946,18 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww) d += __shfl(part, (tid & 63 & ~7) | ww);
             if (live && sub == 0) {
-                const float inv_row = p.inv_norm[row];
-                const float scale = inv_row * qinv;
+                const float scale = p.inv_norm[row] * qinv;
                 float sc = d * scale;
                 sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);
                 if (scale > 0.f && sc == sc) {
                     const uint32_t u = __float_as_uint(sc);
                     const uint32_t ord = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
-                    const int slot = atomicAdd(&s_nbest, 1);
-                    best[slot] = mk64(ord, ~row);
+                    best[atomicAdd(&s_nbest, 1)] = mk64(ord, ~row);
                 }
-                atomicAdd(&s_rescored, 1);
             }
         }
         __syncthreads();
+        if (tid == 0) s_rescored += ns;
         if (r0 + FIN_ROUND < C && s_nbest > k) {  // more rounds follow: keep only the running top-k
             const int B = s_nbest;
             uint64_t mine[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
