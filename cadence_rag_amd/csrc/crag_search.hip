@@ -1556,6 +1556,47 @@ __device__ __forceinline__ uint32_t sort32_desc_u32(uint32_t v, int lane) {
     return v;
 }
 
+// (rank+1)-th largest (rank = 0 .. 32*S-1) of the 32*S values a half-wave holds, S per lane: bitonic sort of the
+// elements i = s*32 + (lane & 31), descending; exchanges at distance >= 32 stay inside the lane.
+template <int S>
+__device__ __forceinline__ uint32_t kth_largest_cells(uint32_t (&v)[S], int rank, int lane) {
+    constexpr int N = 32 * S;
+    static_for<1, 8>([&](auto LS) {  // block size 2^LS
+        constexpr int size = 1 << decltype(LS)::value;
+        if constexpr (size <= N) {
+            static_for<0, decltype(LS)::value>([&](auto LT) {
+                constexpr int stride = size >> (1 + decltype(LT)::value);
+                if constexpr (stride >= 32) {
+                    constexpr int ds = stride >> 5;
+#pragma unroll
+                    for (int s0 = 0; s0 < S; ++s0) {
+                        if ((s0 & ds) == 0) {
+                            const bool desc = size >= N || ((s0 * 32) & size) == 0;  // uniform: size >= 64 here
+                            const uint32_t a = v[s0], b = v[s0 | ds];
+                            const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+                            v[s0] = desc ? hi : lo;
+                            v[s0 | ds] = desc ? lo : hi;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int s0 = 0; s0 < S; ++s0) {
+                        const int i = s0 * 32 + (lane & 31);
+                        const bool desc = size >= N || (i & size) == 0;
+                        const bool keep_max = desc == ((lane & stride) == 0);
+                        const uint32_t o = swz_xor<stride>(v[s0]);
+                        v[s0] = keep_max ? (o > v[s0] ? o : v[s0]) : (o < v[s0] ? o : v[s0]);
+                    }
+                }
+            });
+        }
+    });
+    uint32_t r = v[0];
+#pragma unroll
+    for (int s0 = 1; s0 < S; ++s0) r = ((rank >> 5) == s0) ? v[s0] : r;
+    return (uint32_t)__shfl((int)r, (lane & 32) | (rank & 31));
+}
+
 template <int NQB>
 struct PfLds {
     typedef float slab_t __attribute__((ext_vector_type(2 * NQB)));
@@ -1663,25 +1704,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
     }
-    float stash[RPO];  // the first tile's scores (NaN = not eligible): judged at the end, when bounds exist
+    // Candidate decisions lag the scores: tile t is judged at the end of iteration t+1, with the bounds read at its
+    // start (every workgroup's publishes of tile t-1 and most of tile t have landed by then), and the first tile,
+    // scored before any bound exists, is judged last of all.  NaN = not eligible.
+    float stash[RPO], prev[RPO];
 #pragma unroll
-    for (int e = 0; e < RPO; ++e) stash[e] = __uint_as_float(0x7fc00000u);
-    uint32_t stash_row = 0u;
+    for (int e = 0; e < RPO; ++e) stash[e] = prev[e] = __uint_as_float(0x7fc00000u);
+    uint32_t stash_row = 0u, prev_row = 0u;
     float inv_cur = 0.f;
     if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
     __syncthreads();
 
-    // k_s of set s: the (k_s)-th largest class maximum of the set is reached by k_s distinct rows (SETS <= k)
-    const int k_base = p.k / SETS, k_rem = p.k % SETS;
     const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
 
-    // Bounds.  p.tau[q] (orderable score, monotone, atomic max) is the best lower bound on the k-th best
-    // approximate score of query q any wave has derived so far; every tile reads it (one word per owned query).
-    // A wave DERIVES bounds only on its refresh tiles (the first two, then every REFRESH-th, staggered over the
-    // workgroups so that some workgroup refreshes on every tile): it loads the class maxima of its queries,
-    // takes per set the (k_s)-th largest of the 32 (half-wave sort) and the minimum over the sets.
+    // Bounds.  The 32*SETS class maxima of a query (class = row position mod 32*SETS: lane x tile parity) belong to
+    // distinct rows, so their k-th largest is a lower bound on the k-th best approximate score.  p.tau[q]
+    // (orderable score, monotone, atomic max) is the best such bound any wave has derived so far; every tile reads
+    // it (one word per owned query).  A wave DERIVES bounds only on its refresh tiles (the first three, then every
+    // REFRESH-th, staggered over the workgroups so that some workgroup refreshes on every tile): it loads the
+    // class maxima of its queries and selects the k-th largest with a half-wave bitonic sort.
     constexpr int REFRESH = 4 * SETS;
     uint32_t *const tau_ptr = p.tau + o.qg0;
     auto load_tau = [&](uint32_t (&tau)[RPO]) {
@@ -1698,23 +1741,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                                ? __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                : 0u;
     };
-    auto derive = [&](const uint32_t (&gb)[RPO][SETS], uint32_t (&tau)[RPO]) {
+    auto derive = [&](uint32_t (&gb)[RPO][SETS], uint32_t (&tau)[RPO]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
-            uint32_t t = 0xffffffffu;
-#pragma unroll
-            for (int s = 0; s < SETS; ++s) {
-                const uint32_t sorted = sort32_desc_u32(gb[e][s], lane);
-                const int ks = k_base + (s < k_rem ? 1 : 0);
-                const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
-                t = kth < t ? kth : t;
-            }
+            const uint32_t t = kth_largest_cells<SETS>(gb[e], p.k - 1, lane);
             if (t > tau[e]) {  // uniform over the half-wave
                 tau[e] = t;
                 if (j == 0) (void)__hip_atomic_fetch_max(tau_ptr + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
+    auto threshold = [&](uint32_t tau) { return tau == 0u ? -__builtin_inff() : ord2f(tau) - 2.f * PF_DELTA; };
 
     int buf = 0;
     for (int ti = 0; ti < c.n_tiles; ++ti) {
@@ -1731,7 +1768,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
                               : 0xffffffffu;
         load_tau(tau);
-        const bool refresh = (ti < 2) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
+        const bool refresh = (ti < 3) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
         if (refresh) load_bounds(gb);
 
         f32x16 acc[NQB];
@@ -1762,7 +1799,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         }
         // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
         if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        float sc[RPO], thr[RPO];
+        float sc[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
 #pragma unroll
@@ -1783,25 +1820,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
             // Class maxima: only a row above the current bound can lift the k-th largest class maximum, so only
             // such rows (the candidates, a few dozen per query and search) are published.  While no bound exists
-            // everything qualifies: then one workgroup in eight publishes a class, which fills every class
-            // 32 times over instead of 256 (an atomic storm on 32 cells per query otherwise).
-            const bool lift = tau[e] != 0u ? (ord > tau[e]) : (ord != 0u && (((c.g + j) & 7) == 0));
+            // everything qualifies: then one workgroup in eight (another eighth on every tile) publishes a class,
+            // which fills every class 32 times over instead of 256 (an atomic storm on 32 cells per query otherwise).
+            const bool lift = tau[e] != 0u ? (ord > tau[e]) : (ord != 0u && (((c.g + j + ti) & 7) == 0));
             if (lift)
                 (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
-            thr[e] = tau[e] == 0u ? -__builtin_inff() : ord2f(tau[e]) - 2.f * PF_DELTA;
-            pass[e] = sc[e] >= thr[e];
+            pass[e] = prev[e] >= threshold(tau[e]);  // the PREVIOUS tile against this iteration's bound
         }
-        if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
+        if (ti > 1) pf_stage<NQB>(L, o, prev, pass, prev_row, p.flags);
+        if (ti == 0) {
 #pragma unroll
             for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
             stash_row = (uint32_t)(row - c.t_begin * 32);
         } else {
-            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) prev[e] = sc[e];
+            prev_row = (uint32_t)(row - c.t_begin * 32);
         }
         inv_cur = inv_nxt;
     }
-    if (c.n_tiles > 0) {  // the first tile against the final bounds
+    if (c.n_tiles > 0) {  // the last tile and the first one against the final bounds
         if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
         uint32_t gb[RPO][SETS], tau[RPO];
         load_tau(tau);
@@ -1809,8 +1848,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         derive(gb, tau);
         bool pass[RPO];
 #pragma unroll
-        for (int e = 0; e < RPO; ++e)
-            pass[e] = stash[e] >= (tau[e] == 0u ? -__builtin_inff() : ord2f(tau[e]) - 2.f * PF_DELTA);
+        for (int e = 0; e < RPO; ++e) pass[e] = prev[e] >= threshold(tau[e]);
+        pf_stage<NQB>(L, o, prev, pass, prev_row, p.flags);
+        if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= threshold(tau[e]);
         pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
     }
     pf_flush<NQB>(p, L, c.t_begin * 32);

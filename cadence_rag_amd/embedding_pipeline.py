@@ -110,27 +110,35 @@ def infer_batch_size_limit(error_message: str) -> Optional[int]:
     return None
 
 
-def _embed_texts_adaptive(texts: Sequence[str], batch_size: int) -> EmbeddingResult:
+def _embed_texts_adaptive(texts: Sequence[str], batch_size: int, on_device: bool = False):
+    """on_device: the vectors stay on the GPU (embeddings.embed_texts_device) and come back as ONE float32
+    [n, dim] tensor in a DeviceEmbeddingResult; the downshift-and-retry rule is the same."""
     cleaned = [t.strip() for t in texts if isinstance(t, str) and t.strip()]
     if not cleaned:
         raise EmbeddingClientError("embedding request requires at least one non-empty text")
     step = max(1, int(batch_size))
-    vectors: List[List[float]] = []
+    vectors: list = []
     model = settings.embeddings_model_id
     pos = 0
     while pos < len(cleaned):
         part = cleaned[pos:pos + step]
         try:
-            res = embed_texts(part)
+            res = _emb.embed_texts_device(part) if on_device else embed_texts(part)
         except EmbeddingClientError as exc:
             if len(part) <= 1:
                 raise
             hinted = infer_batch_size_limit(str(exc))
             step = max(1, hinted) if (hinted is not None and hinted < len(part)) else max(1, len(part) // 2)
             continue  # retry the same position with the smaller batch
-        vectors.extend(res.vectors)
+        if on_device:
+            vectors.append(res.vectors)
+        else:
+            vectors.extend(res.vectors)
         model = res.model
         pos += len(part)
+    if on_device:
+        import torch
+        return _emb.DeviceEmbeddingResult(vectors=vectors[0] if len(vectors) == 1 else torch.cat(vectors), model=model)
     return EmbeddingResult(vectors=vectors, model=model)
 
 
@@ -169,7 +177,9 @@ def _backfill_table(spec: TableSpec, *, batch_size: int, call_id: Optional[UUID]
         batch = _fetch_pending_rows(spec, batch_size, call_id=call_id)
         if not batch:
             break
-        res = _embed_texts_adaptive([r.content for r in batch], batch_size=batch_size)
+        # a store that keeps vectors in HBM takes them as a device tensor: no per-float Python objects at all
+        on_device = bool(getattr(_require_store(), "device_vectors", False))
+        res = _embed_texts_adaptive([r.content for r in batch], batch_size=batch_size, on_device=on_device)
         _update_embeddings(spec, batch, res.vectors)
         touched.update(r.call_id for r in batch)
         updated += len(batch)
@@ -244,3 +254,22 @@ class InMemoryStore:
                               "ner_config": json.dumps(NER_CONFIG_DISABLED)})
             n += 1
         return n
+
+
+class DeviceSinkStore(InMemoryStore):
+    """BackfillStore whose vectors never leave the GPU: run_embedding_backfill sees `device_vectors`, embeds with
+    embeddings.embed_texts_device and hands update_embeddings ONE float32 [n, dim] CUDA tensor, which goes to
+    the table's sink (a DenseIndex, or DenseTable.sink(...)) as a device pointer -> crag_index_add.  The row
+    dictionaries only record that the row is embedded (and where).  This removes the reference's per-row
+    15 KB text literal (embedding_pipeline.py:157-168) AND the host float lists from the write path."""
+
+    device_vectors = True
+
+    def update_embeddings(self, spec, rows, vectors):
+        sink = self.sinks.get(spec.table)
+        if sink is None:
+            raise RuntimeError(f"DeviceSinkStore has no sink for table {spec.table!r}")
+        if rows:
+            sink.add(vectors, ids=[r.row_id for r in rows])
+        for row in rows:
+            self.tables[spec.table][row.row_id]["embedding"] = "hbm"

@@ -27,9 +27,18 @@ class EmbeddingResult:
     model: str
 
 
+@dataclass(frozen=True)
+class DeviceEmbeddingResult:
+    """embed_texts_device's result: `vectors` is a float32 [n, embeddings_dim] tensor that stays on the encoder's
+    GPU (the backfill hands it to crag_index_add as a device pointer; nothing is converted to Python floats)."""
+    vectors: "object"
+    model: str
+
+
 class Encoder(Protocol):
     """In-process backend: texts -> ([n][dim] vectors, model id).  May raise any exception; it is
-    reported as EmbeddingClientError (the reference's callers only catch that type)."""
+    reported as EmbeddingClientError (the reference's callers only catch that type).  An encoder may also offer
+    encode_device(texts) -> (float32 CUDA tensor [n, dim], model id)."""
 
     def encode(self, texts: Sequence[str]) -> Tuple[Sequence[Sequence[float]], str]: ...
 
@@ -117,6 +126,31 @@ def embed_texts(texts: Sequence[str]) -> EmbeddingResult:
         raise EmbeddingClientError(
             f"embedding response count mismatch: got {len(raw)}, expected {len(cleaned)}")
     return EmbeddingResult(vectors=_validate_vectors(raw), model=model)
+
+
+def embed_texts_device(texts: Sequence[str]) -> DeviceEmbeddingResult:
+    """embed_texts for consumers that keep the vectors on the GPU (the HBM index sink of the backfill): same
+    guards, text validation and error strings, but the native encoder's output tensor is returned as it is —
+    no .tolist(), no per-float validation loop (the dim check is the tensor's shape)."""
+    if not embeddings_enabled():
+        raise EmbeddingClientError("EMBEDDINGS_BASE_URL is not configured")
+    cleaned = _validate_texts(texts)
+    enc = _encoder
+    if not _is_native(settings.embeddings_base_url) or enc is None or not hasattr(enc, "encode_device"):
+        raise EmbeddingClientError("device-resident embeddings need the native encoder (EMBEDDINGS_BASE_URL=native)")
+    try:
+        with _encoder_lock:
+            vecs, model = enc.encode_device(cleaned)
+    except EmbeddingClientError:
+        raise
+    except Exception as exc:  # noqa: BLE001 - callers rely on a single error type
+        raise EmbeddingClientError(f"native embedding encoder failed: {exc}") from exc
+    if int(vecs.shape[0]) != len(cleaned):
+        raise EmbeddingClientError(
+            f"embedding response count mismatch: got {int(vecs.shape[0])}, expected {len(cleaned)}")
+    if vecs.dim() != 2 or int(vecs.shape[1]) != settings.embeddings_dim:
+        raise EmbeddingClientError(f"embedding 0 has dim {int(vecs.shape[-1])}; expected {settings.embeddings_dim}")
+    return DeviceEmbeddingResult(vectors=vecs, model=model)
 
 
 def embed_texts_batched(texts: Sequence[str], batch_size: Optional[int] = None) -> EmbeddingResult:

@@ -261,12 +261,16 @@ class Qwen3Encoder:
         return self.forward_packed(ids, batch)
 
     # -- the Encoder protocol of cadence_rag_amd.embeddings ------------------------------------------
-    def encode(self, texts: Sequence[str]) -> Tuple[List[List[float]], str]:
+    def encode_device(self, texts: Sequence[str]) -> Tuple[torch.Tensor, str]:
+        """texts -> unit-norm embeddings [n, out_dim] fp32 ON THE DEVICE (embeddings.embed_texts_device)."""
         if self.tokenizer is None:
             raise RuntimeError("no tokenizer loaded (Qwen3Encoder.from_pretrained, or set .tokenizer)")
         enc = self.tokenizer(list(texts), truncation=True, max_length=self.cfg.max_length, padding=False)["input_ids"]
-        vecs = self.embed_token_lists(enc)
-        return vecs.cpu().tolist(), self.cfg.model_id
+        return self.embed_token_lists(enc), self.cfg.model_id
+
+    def encode(self, texts: Sequence[str]) -> Tuple[List[List[float]], str]:
+        vecs, model = self.encode_device(texts)
+        return vecs.cpu().tolist(), model
 
 
 class ByteTokenizer:

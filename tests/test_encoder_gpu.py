@@ -426,6 +426,23 @@ def test_backfill_through_native_encoder_into_hbm_index(gpu, monkeypatch):
         # a second run finds nothing left to do
         again = ep.run_embedding_backfill(batch_size=256)
         assert again.rows_updated == 0
+        # the device-resident form of the same job: embed_texts_device -> one CUDA tensor per batch -> the sink's
+        # crag_index_add with a device pointer; no Python float is ever made.  Same batches, same kernels: the
+        # rows in HBM equal the host-list run's.
+        tables2 = {name: {i: dict(r, embedding=None) for i, r in t.items()} for name, t in tables.items()}
+        dev_chunks, dev_arts = DenseIndex(1024, capacity=n_chunks), DenseIndex(1024, capacity=n_art)
+        try:
+            ep.set_store(ep.DeviceSinkStore(tables2, sinks={"chunks": dev_chunks, "artifact_chunks": dev_arts}))
+            seen_batches.clear()
+            s2 = ep.run_embedding_backfill(batch_size=256)
+            assert s2.rows_updated == summary.rows_updated and s2.per_table == summary.per_table
+            assert seen_batches == []      # enc.encode (the list-returning form) is not on this path
+            rows2, ids2 = dev_chunks.get_rows(0, len(dev_chunks))
+            assert np.array_equal(ids2, ids) and np.allclose(rows2, rows, atol=1e-6)
+            assert all(r["embedding"] == "hbm" for i, r in tables2["chunks"].items() if i != 1003)
+        finally:
+            dev_chunks.close()
+            dev_arts.close()
     finally:
         embeddings.set_encoder(None)
         ep.set_store(None)
