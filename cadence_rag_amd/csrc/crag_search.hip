@@ -1769,7 +1769,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                               : 0xffffffffu;
         load_tau(tau);
         const bool refresh = (ti < 3) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
-        if (refresh) load_bounds(gb);
+        // loaded on every tile although only refresh tiles use them: a load under a branch makes the number of
+        // outstanding loads path-dependent, and the compiler then waits for the whole prefetch ring at every use
+        load_bounds(gb);
 
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
