@@ -50,7 +50,11 @@ struct MergeParams {
 };
 
 // ---- prefilter path (fp16 MFMA scan + exact rescoring), see crag_search.hip --------------------------------
-constexpr int PF_BOUND_CELLS = 128;           // class maxima per query: 4 sets x 32 row classes
+// per-query bound record: 128 class maxima (4 sets x 32 row classes), then the shared bound tau in a line of its
+// own -- every wave of every workgroup reads tau on every tile: 64 taus packed into two cache lines made those
+// two lines a hot spot that cost 10-20 us per tile
+constexpr int PF_BOUND_CELLS = 160;
+constexpr int PF_TAU_CELL = 128;
 constexpr int PF_MIN_ROWS_PER_GROUP = 128;    // below this many rows per workgroup the plain fp32 scan is used
 
 struct PrepParams {
@@ -60,7 +64,6 @@ struct PrepParams {
     float *a32;               // [nq_pad/32][8 waves][16][64] float4: raw queries in fp32 A-fragment order
     _Float16 *a16;            // nullable; [nq_pad/32][8 waves][8][64][8]: unit queries in fp16 A-fragment order
     uint32_t *pf_gbound;      // nullable; [nq_pad][PF_BOUND_CELLS], zeroed here
-    uint32_t *pf_tau;         // [nq_pad] best bound on the k-th best approximate score, zeroed here
     uint32_t *pf_count;       // [nq_pad] candidates per query, zeroed here
     uint32_t *pf_flags;       // [4]: [0] = a candidate list overflowed, zeroed here
 };
@@ -72,8 +75,7 @@ struct PfParams {
     const float *qinv;
     const uint32_t *mask;
     int64_t mask_stride_w;
-    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS] class maxima (orderable scores, atomic max)
-    uint32_t *tau;            // [nq_pad] shared bound per query (orderable score, atomic max)
+    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS] class maxima + tau (orderable scores, atomic max)
     uint2 *cand;              // [nq_pad][cap]: x = orderable approximate score, y = row position
     uint32_t *count;          // [nq_pad]
     uint32_t *flags;
