@@ -96,7 +96,7 @@ struct crag_index {
         bool in_use = false;
         DevBuf partial, gbound;
         // prepared queries (fragment order) and the prefilter path's per-query state
-        DevBuf a32, a16, qinv, pf_gbound, pf_tau, pf_cand, pf_count, pf_flags;
+        DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags;
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
         uint64_t last_use = 0;
     } ws[MAX_WS];
@@ -193,7 +193,6 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         if ((rc = ws->pf_gbound.ensure((size_t)nq_pad * crag::PF_BOUND_CELLS * sizeof(uint32_t)))) return rc;
         if ((rc = ws->pf_cand.ensure((size_t)nq_pad * cap * sizeof(uint2)))) return rc;
         if ((rc = ws->pf_count.ensure((size_t)nq_pad * sizeof(uint32_t)))) return rc;
-        if ((rc = ws->pf_tau.ensure((size_t)nq_pad * sizeof(uint32_t)))) return rc;
         if ((rc = ws->pf_flags.ensure(4 * sizeof(uint32_t)))) return rc;
     }
 
@@ -227,7 +226,6 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     pp.a16 = prefilter ? (_Float16 *)ws->a16.p : nullptr;
     pp.pf_gbound = prefilter ? (uint32_t *)ws->pf_gbound.p : nullptr;
     pp.pf_count = prefilter ? (uint32_t *)ws->pf_count.p : nullptr;
-    pp.pf_tau = prefilter ? (uint32_t *)ws->pf_tau.p : nullptr;
     pp.pf_flags = prefilter ? (uint32_t *)ws->pf_flags.p : nullptr;
     HIP_TRY(crag::launch_prep_queries(pp, nq_pad, st));
 
@@ -279,7 +277,6 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.mask = (const uint32_t *)d_mask;
         fp.mask_stride_w = mask_stride / 4;
         fp.gbound = (uint32_t *)ws->pf_gbound.p;
-        fp.tau = (uint32_t *)ws->pf_tau.p;
         fp.cand = (uint2 *)ws->pf_cand.p;
         fp.count = (uint32_t *)ws->pf_count.p;
         fp.flags = (uint32_t *)ws->pf_flags.p;
@@ -442,7 +439,6 @@ int crag_index_destroy(crag_index *ix) {
         w.a16.release();
         w.qinv.release();
         w.pf_gbound.release();
-        w.pf_tau.release();
         w.pf_cand.release();
         w.pf_count.release();
         w.pf_flags.release();

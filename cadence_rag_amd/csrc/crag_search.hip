@@ -1490,7 +1490,6 @@ constexpr float PF_DELTA = 1.25e-3f;
 // truncates, + the fp32 normalisations 4 * 2^-24; sum 1.105e-3 (the difference between the fp32 chain and the
 // real-number cosine, < 2e-6, included).  tests/test_prefilter_gpu.py measures the actual worst case.
 constexpr int PF_STAGE = 3072;   // per-workgroup candidate staging entries in LDS (flushed above 1024)
-constexpr int PF_MAX_SETS = 4;
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1533,11 +1532,8 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(PrepParams p) {
         *reinterpret_cast<f16x4 *>(dst) = f16x4{l2[0], l2[1], h2[0], h2[1]};
     }
     if (p.pf_gbound) {
-        if (t < PF_MAX_SETS * 32) p.pf_gbound[(size_t)q * (PF_MAX_SETS * 32) + t] = 0u;
-        if (t == 0) {
-            p.pf_count[q] = 0u;
-            p.pf_tau[q] = 0u;
-        }
+        if (t < PF_BOUND_CELLS) p.pf_gbound[(size_t)q * PF_BOUND_CELLS + t] = 0u;
+        if (t == 0) p.pf_count[q] = 0u;
         if (q == 0 && t < 4) p.pf_flags[t] = 0u;
     }
 }
@@ -1720,17 +1716,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
 
     // Bounds.  The 32*SETS class maxima of a query (class = row position mod 32*SETS: lane x tile parity) belong to
-    // distinct rows, so their k-th largest is a lower bound on the k-th best approximate score.  p.tau[q]
+    // distinct rows, so their k-th largest is a lower bound on the k-th best approximate score.  tau[q] (cell PF_TAU_CELL of the query's record)
     // (orderable score, monotone, atomic max) is the best such bound any wave has derived so far; every tile reads
     // it (one word per owned query).  A wave DERIVES bounds only on its refresh tiles (the first three, then every
     // REFRESH-th, staggered over the workgroups so that some workgroup refreshes on every tile): it loads the
     // class maxima of its queries and selects the k-th largest with a half-wave bitonic sort.
     constexpr int REFRESH = 4 * SETS;
-    uint32_t *const tau_ptr = p.tau + o.qg0;
+    uint32_t *const tau_ptr = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + PF_TAU_CELL;  // + e * PF_BOUND_CELLS
     auto load_tau = [&](uint32_t (&tau)[RPO]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
-            tau[e] = ((o.okmask >> e) & 1u) ? __hip_atomic_load(tau_ptr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            tau[e] = ((o.okmask >> e) & 1u) ? __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     };
     auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
@@ -1747,7 +1743,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             const uint32_t t = kth_largest_cells<SETS>(gb[e], p.k - 1, lane);
             if (t > tau[e]) {  // uniform over the half-wave
                 tau[e] = t;
-                if (j == 0) (void)__hip_atomic_fetch_max(tau_ptr + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j == 0) (void)__hip_atomic_fetch_max(tau_ptr + e * PF_BOUND_CELLS, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
