@@ -1723,19 +1723,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // class maxima of its queries and selects the k-th largest with a half-wave bitonic sort.
     constexpr int REFRESH = 4 * SETS;
     uint32_t *const tau_ptr = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + PF_TAU_CELL;  // + e * PF_BOUND_CELLS
+    // Every load inside the tile loop is issued unconditionally (a padded query reads the record of a padded
+    // query, which exists; the value is masked afterwards): with a load under a branch the compiler cannot count
+    // the outstanding loads and waits for far more than it needs, which puts these small device-coherent loads
+    // on the critical path of the corpus stream.
     auto load_tau = [&](uint32_t (&tau)[RPO]) {
 #pragma unroll
-        for (int e = 0; e < RPO; ++e)
-            tau[e] = ((o.okmask >> e) & 1u) ? __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int e = 0; e < RPO; ++e) {
+            const uint32_t v = __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tau[e] = ((o.okmask >> e) & 1u) ? v : 0u;
+        }
     };
     auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
 #pragma unroll
-            for (int s = 0; s < SETS; ++s)
-                gb[e][s] = ((o.okmask >> e) & 1u)
-                               ? __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : 0u;
+            for (int s = 0; s < SETS; ++s) {
+                const uint32_t v = __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gb[e][s] = ((o.okmask >> e) & 1u) ? v : 0u;
+            }
     };
     auto derive = [&](uint32_t (&gb)[RPO][SETS], uint32_t (&tau)[RPO]) {
 #pragma unroll
@@ -1756,18 +1762,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         const int64_t row = tile * 32 + j;
         // operands of this tile's epilogue: issued behind the B loads of this tile (already in flight) and in
         // front of the next tile's, so they have arrived when the MFMA phase ends
-        float inv_nxt = 0.f;
-        if (ti + 1 < c.n_tiles) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1)) * 32 + j];
+        const int ti_nxt = ti + 1 < c.n_tiles ? ti + 1 : ti;  // the last iteration re-reads its own tile: no branch
+        const float inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti_nxt)) * 32 + j];
         uint32_t mword[RPO], tau[RPO], gb[RPO][SETS];
 #pragma unroll
-        for (int e = 0; e < RPO; ++e)
-            mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
-                              : 0xffffffffu;
+        for (int e = 0; e < RPO; ++e) {
+            // without a mask the load goes to the bound record (any readable word): again no branch around a load
+            const uint32_t *mp = p.mask ? p.mask + (size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile
+                                        : gb_row;
+            const uint32_t mv = *mp;
+            mword[e] = p.mask ? mv : 0xffffffffu;
+        }
         load_tau(tau);
         const bool refresh = (ti < 3) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
-        // loaded on every tile although only refresh tiles use them: a load under a branch makes the number of
-        // outstanding loads path-dependent, and the compiler then waits for the whole prefetch ring at every use
-        load_bounds(gb);
+        load_bounds(gb);  // on every tile, although only refresh tiles use them (see above)
 
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
