@@ -190,7 +190,14 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     const int cap = 8192;  // candidates per query; a fuller list sets the overflow flag -> gated fp32 scan
     if (prefilter) {
         if ((rc = ws->a16.ensure((size_t)nq_pad * crag::DIM * 2))) return rc;
-        if ((rc = ws->pf_gbound.ensure((size_t)nq_pad * crag::PF_BOUND_CELLS * sizeof(uint32_t)))) return rc;
+        {   // the queries' bound records (zeroed by the prep kernel on every search) + one idle record of zeros
+            // per workgroup that nothing ever writes (zeroed once, when the buffer is allocated)
+            const size_t need = (size_t)(nq_pad + G) * crag::PF_BOUND_CELLS * sizeof(uint32_t);
+            if (need > ws->pf_gbound.bytes) {
+                if ((rc = ws->pf_gbound.ensure(need))) return rc;
+                HIP_TRY(hipMemsetAsync(ws->pf_gbound.p, 0, ws->pf_gbound.bytes, st));
+            }
+        }
         if ((rc = ws->pf_cand.ensure((size_t)nq_pad * cap * sizeof(uint2)))) return rc;
         if ((rc = ws->pf_count.ensure((size_t)nq_pad * sizeof(uint32_t)))) return rc;
         if ((rc = ws->pf_flags.ensure(4 * sizeof(uint32_t)))) return rc;

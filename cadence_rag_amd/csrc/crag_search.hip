@@ -1489,7 +1489,8 @@ constexpr float PF_DELTA = 1.25e-3f;
 // + fp32 accumulation of 1024 exact products and 7 partial sums, <= 1031 * 2^-23 = 1.23e-4 even if every add
 // truncates, + the fp32 normalisations 4 * 2^-24; sum 1.105e-3 (the difference between the fp32 chain and the
 // real-number cosine, < 2e-6, included).  tests/test_prefilter_gpu.py measures the actual worst case.
-constexpr int PF_STAGE = 3072;   // per-workgroup candidate staging entries in LDS (flushed above 1024)
+constexpr int PF_FLUSH_ABOVE = 768;                // staged candidates that trigger a flush at the next tile boundary
+constexpr int PF_STAGE = PF_FLUSH_ABOVE + 2048;    // per-workgroup staging entries in LDS: a tile adds at most 32 x 64
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1598,6 +1599,7 @@ struct PfLds {
     typedef float slab_t __attribute__((ext_vector_type(2 * NQB)));
     slab_t slab[2][SCAN_WAVES][SCAN_WAVES][64];  // [buf][owner wave][producer wave][lane]: split-K partial sums
     uint2 stage[PF_STAGE];                       // staged candidates: x = orderable score, y = (row - window) << 6 | query
+    float stash[SCAN_WAVES][2 * NQB][64];       // the first tile's scores, judged when the scan is over
     uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
     uint32_t n_stage;
 };
@@ -1624,7 +1626,7 @@ __device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, c
                 atomicAdd(&L.qcount[o.ql0 + e], 1u);
                 L.stage[slot] = make_uint2(f2ord(sc[e]), (row_in_window << 6) | (uint32_t)(o.ql0 + e));
             } else {
-                *flags = 1u;  // cannot happen (<= 1024 staged + <= 2048 per tile); never drop a candidate silently
+                *flags = 1u;  // cannot happen (<= PF_FLUSH_ABOVE staged + <= 2048 per tile); never drop one silently
             }
         }
     }
@@ -1665,7 +1667,17 @@ template <int NQB, int SETS>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB;
     __shared__ PfLds<NQB> L;
-    const ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
+    // row range of this workgroup: whole tiles (a partial tile costs a full trip through the loop here, where a
+    // trip is bound by memory latency, not by bytes), n_tiles_total split as evenly as whole tiles allow
+    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
+    {
+        const int64_t nt = (p.n_rows + 31) >> 5;
+        c.t_begin = (nt * c.g) / p.G;
+        const int64_t t_end = (nt * (c.g + 1)) / p.G;
+        c.n_tiles = (int)(t_end - c.t_begin);
+        c.r_begin = c.t_begin * 32;
+        c.r_end = t_end * 32 < p.n_rows ? t_end * 32 : p.n_rows;
+    }
     const int lane = c.lane, w = c.w, j = c.j, h = c.h;
 
     PfOwner<NQB> o;
@@ -1700,13 +1712,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
     }
-    // Candidate decisions lag the scores: tile t is judged at the end of iteration t+1, with the bounds read at its
-    // start (every workgroup's publishes of tile t-1 and most of tile t have landed by then), and the first tile,
-    // scored before any bound exists, is judged last of all.  NaN = not eligible.
-    float stash[RPO], prev[RPO];
+    // Candidate decisions lag the scores: tile t is judged at the end of iteration t+1, with the bound known then
+    // (every workgroup's publishes of tile t-1 and most of tile t have landed), and the first tile, scored before
+    // any bound exists, waits in LDS and is judged last of all.  NaN = not eligible.
+    float prev[RPO];
+    uint32_t tau[RPO];  // this wave's view of the bounds of its queries (orderable scores; 0 = none yet)
 #pragma unroll
-    for (int e = 0; e < RPO; ++e) stash[e] = prev[e] = __uint_as_float(0x7fc00000u);
-    uint32_t stash_row = 0u, prev_row = 0u;
+    for (int e = 0; e < RPO; ++e) {
+        prev[e] = __uint_as_float(0x7fc00000u);
+        tau[e] = 0u;
+        L.stash[w][e][lane] = __uint_as_float(0x7fc00000u);
+    }
     float inv_cur = 0.f;
     if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
@@ -1714,49 +1730,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 
     const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
+    uint32_t *const tau_ptr = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + PF_TAU_CELL;  // + e * PF_BOUND_CELLS
+    // a record of zeros nobody writes, one per workgroup (behind the queries' records): where the bound loads of a
+    // non-refresh tile go
+    const uint32_t *const idle_row = p.gbound + ((size_t)gridDim.y * (32 * NQB) + c.g) * PF_BOUND_CELLS + j;
 
     // Bounds.  The 32*SETS class maxima of a query (class = row position mod 32*SETS: lane x tile parity) belong to
-    // distinct rows, so their k-th largest is a lower bound on the k-th best approximate score.  tau[q] (cell PF_TAU_CELL of the query's record)
-    // (orderable score, monotone, atomic max) is the best such bound any wave has derived so far; every tile reads
-    // it (one word per owned query).  A wave DERIVES bounds only on its refresh tiles (the first three, then every
-    // REFRESH-th, staggered over the workgroups so that some workgroup refreshes on every tile): it loads the
-    // class maxima of its queries and selects the k-th largest with a half-wave bitonic sort.
+    // distinct rows, so their k-th largest is a lower bound on the k-th best approximate score; the shared cell tau
+    // of the query's record keeps the best such bound any wave has derived (atomic max).  A wave touches these
+    // device-coherent words only on its REFRESH tiles (the first three, then every REFRESH-th, staggered over the
+    // workgroups so that some workgroups refresh on every tile): it loads tau and the class maxima of its queries,
+    // selects the k-th largest with a half-wave bitonic sort and publishes an improvement.  In between it works
+    // with its own copy.  [Reading them on every tile made 256 workgroups hit the same 64 cache lines at once;
+    // the requests serialise per line (~25 ns each), loads return in order, and the corpus stream behind them
+    // waited: 6.9 us per tile instead of 5.3.]
+    // The load INSTRUCTIONS are issued on every tile all the same, on the other tiles to the idle record (zeros, a
+    // line no other workgroup reads): a load under a branch would make the number of outstanding loads
+    // path-dependent, and the compiler then waits for far more than it needs at every use of the corpus ring.
     constexpr int REFRESH = 4 * SETS;
-    uint32_t *const tau_ptr = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + PF_TAU_CELL;  // + e * PF_BOUND_CELLS
-    // Every load inside the tile loop is issued unconditionally (a padded query reads the record of a padded
-    // query, which exists; the value is masked afterwards): with a load under a branch the compiler cannot count
-    // the outstanding loads and waits for far more than it needs, which puts these small device-coherent loads
-    // on the critical path of the corpus stream.
-    auto load_tau = [&](uint32_t (&tau)[RPO]) {
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) {
-            const uint32_t v = __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tau[e] = ((o.okmask >> e) & 1u) ? v : 0u;
-        }
-    };
-    auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
-#pragma unroll
-        for (int e = 0; e < RPO; ++e)
-#pragma unroll
-            for (int s = 0; s < SETS; ++s) {
-                const uint32_t v = __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gb[e][s] = ((o.okmask >> e) & 1u) ? v : 0u;
-            }
-    };
-    auto derive = [&](uint32_t (&gb)[RPO][SETS], uint32_t (&tau)[RPO]) {
+    auto derive = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
             const uint32_t t = kth_largest_cells<SETS>(gb[e], p.k - 1, lane);
             if (t > tau[e]) {  // uniform over the half-wave
                 tau[e] = t;
-                if (j == 0) (void)__hip_atomic_fetch_max(tau_ptr + e * PF_BOUND_CELLS, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j == 0)
+                    (void)__hip_atomic_fetch_max(tau_ptr + e * PF_BOUND_CELLS, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
-    auto threshold = [&](uint32_t tau) { return tau == 0u ? -__builtin_inff() : ord2f(tau) - 2.f * PF_DELTA; };
+    auto threshold = [&](uint32_t t) { return t == 0u ? -__builtin_inff() : ord2f(t) - 2.f * PF_DELTA; };
+    auto row_in_window = [&](int ti) { return (uint32_t)(tile_of(c, ti) * 32 + j); };
+    const uint32_t *const no_mask = reinterpret_cast<const uint32_t *>(p.qinv);  // any cold readable word
 
     int buf = 0;
+#pragma clang loop unroll(disable)
     for (int ti = 0; ti < c.n_tiles; ++ti) {
+        const bool refresh = (ti < 3) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
@@ -1764,18 +1774,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         // front of the next tile's, so they have arrived when the MFMA phase ends
         const int ti_nxt = ti + 1 < c.n_tiles ? ti + 1 : ti;  // the last iteration re-reads its own tile: no branch
         const float inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti_nxt)) * 32 + j];
-        uint32_t mword[RPO], tau[RPO], gb[RPO][SETS];
+        uint32_t mword[RPO], gtau[RPO], gb[RPO][SETS];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
-            // without a mask the load goes to the bound record (any readable word): again no branch around a load
-            const uint32_t *mp = p.mask ? p.mask + (size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile
-                                        : gb_row;
+            const bool qok = (o.okmask >> e) & 1u;
+            const uint32_t *mp = p.mask ? p.mask + (size_t)(qok ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile : no_mask;
             const uint32_t mv = *mp;
             mword[e] = p.mask ? mv : 0xffffffffu;
+            const bool live = refresh && qok;
+            const uint32_t *tp = live ? tau_ptr + e * PF_BOUND_CELLS : idle_row;
+            gtau[e] = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int s = 0; s < SETS; ++s) {
+                const uint32_t *gp = live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row;
+                gb[e][s] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        load_tau(tau);
-        const bool refresh = (ti < 3) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
-        load_bounds(gb);  // on every tile, although only refresh tiles use them (see above)
 
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
@@ -1804,7 +1818,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             L.slab[buf][ow][w][lane] = v;
         }
         // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
-        if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
         float sc[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
@@ -1815,7 +1829,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) sc[e] += v[e];
         }
         buf ^= 1;
-        if (refresh) derive(gb, tau);
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) tau[e] = gtau[e] > tau[e] ? gtau[e] : tau[e];  // the idle record reads 0
+        if (refresh) derive(gb);
         const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
         const int set = (int)(tile & (int64_t)(SETS - 1));
         bool pass[RPO];
@@ -1832,34 +1848,47 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             if (lift)
                 (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
-            pass[e] = prev[e] >= threshold(tau[e]);  // the PREVIOUS tile against this iteration's bound
+            pass[e] = prev[e] >= threshold(tau[e]);  // the PREVIOUS tile against the bound known now
         }
-        if (ti > 1) pf_stage<NQB>(L, o, prev, pass, prev_row, p.flags);
+        if (ti > 1) pf_stage<NQB>(L, o, prev, pass, row_in_window(ti - 1), p.flags);
         if (ti == 0) {
 #pragma unroll
-            for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
-            stash_row = (uint32_t)(row - c.t_begin * 32);
+            for (int e = 0; e < RPO; ++e) L.stash[w][e][lane] = sc[e];
         } else {
 #pragma unroll
             for (int e = 0; e < RPO; ++e) prev[e] = sc[e];
-            prev_row = (uint32_t)(row - c.t_begin * 32);
         }
         inv_cur = inv_nxt;
     }
     if (c.n_tiles > 0) {  // the last tile and the first one against the final bounds
-        if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        uint32_t gb[RPO][SETS], tau[RPO];
-        load_tau(tau);
-        load_bounds(gb);
-        derive(gb, tau);
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        uint32_t gb[RPO][SETS];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) {
+            const bool qok = (o.okmask >> e) & 1u;
+            const uint32_t gt = __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tau[e] = (qok && gt > tau[e]) ? gt : tau[e];
+#pragma unroll
+            for (int s = 0; s < SETS; ++s) {
+                const uint32_t v = __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gb[e][s] = qok ? v : 0u;
+            }
+        }
+        derive(gb);
         bool pass[RPO];
+        if (c.n_tiles > 1) {
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = prev[e] >= threshold(tau[e]);
-        pf_stage<NQB>(L, o, prev, pass, prev_row, p.flags);
-        if (__syncthreads_or(L.n_stage > 1024u)) pf_flush<NQB>(p, L, c.t_begin * 32);
+            for (int e = 0; e < RPO; ++e) pass[e] = prev[e] >= threshold(tau[e]);
+            pf_stage<NQB>(L, o, prev, pass, row_in_window(c.n_tiles - 1), p.flags);
+        }
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        float first[RPO];
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= threshold(tau[e]);
-        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
+        for (int e = 0; e < RPO; ++e) {
+            first[e] = L.stash[w][e][lane];
+            pass[e] = first[e] >= threshold(tau[e]);
+        }
+        pf_stage<NQB>(L, o, first, pass, row_in_window(0), p.flags);
     }
     pf_flush<NQB>(p, L, c.t_begin * 32);
 }
