@@ -1600,6 +1600,7 @@ struct PfLds {
     slab_t slab[2][SCAN_WAVES][SCAN_WAVES][64];  // [buf][owner wave][producer wave][lane]: split-K partial sums
     uint2 stage[PF_STAGE];                       // staged candidates: x = orderable score, y = (row - window) << 6 | query
     float stash[SCAN_WAVES][2 * NQB][64];       // the first tile's scores, judged when the scan is over
+    uint32_t tau[SCAN_WAVES][2][2 * NQB];       // each half-wave's view of the bounds of its queries (0 = none yet)
     uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
     uint32_t n_stage;
 };
@@ -1716,11 +1717,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // (every workgroup's publishes of tile t-1 and most of tile t have landed), and the first tile, scored before
     // any bound exists, waits in LDS and is judged last of all.  NaN = not eligible.
     float prev[RPO];
-    uint32_t tau[RPO];  // this wave's view of the bounds of its queries (orderable scores; 0 = none yet)
+    uint32_t *const tau = L.tau[w][h];  // this half-wave's view of the bounds (orderable scores), kept in LDS
 #pragma unroll
     for (int e = 0; e < RPO; ++e) {
         prev[e] = __uint_as_float(0x7fc00000u);
-        tau[e] = 0u;
+        if (j == 0) tau[e] = 0u;
         L.stash[w][e][lane] = __uint_as_float(0x7fc00000u);
     }
     float inv_cur = 0.f;
@@ -1752,10 +1753,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
             const uint32_t t = kth_largest_cells<SETS>(gb[e], p.k - 1, lane);
-            if (t > tau[e]) {  // uniform over the half-wave
+            if (t > tau[e] && j == 0) {
                 tau[e] = t;
-                if (j == 0)
-                    (void)__hip_atomic_fetch_max(tau_ptr + e * PF_BOUND_CELLS, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_max(tau_ptr + e * PF_BOUND_CELLS, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     };
@@ -1763,10 +1763,21 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     auto row_in_window = [&](int ti) { return (uint32_t)(tile_of(c, ti) * 32 + j); };
     const uint32_t *const no_mask = reinterpret_cast<const uint32_t *>(p.qinv);  // any cold readable word
 
+    // The bound words are loaded at the END of an iteration and used in the epilogue of the next one: they then sit
+    // behind the next tile's corpus loads in the (in-order) return queue and can never hold corpus data back,
+    // whatever their latency; a whole MFMA phase later they have arrived.
+    auto is_refresh = [&](int ti) { return (ti < 4) || (((ti + c.g) & (REFRESH - 1)) == 0); };  // uniform over the workgroup
+    uint32_t gtau[RPO], gb[RPO][SETS];
+#pragma unroll
+    for (int e = 0; e < RPO; ++e) {
+        gtau[e] = 0u;
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) gb[e][s] = 0u;
+    }
     int buf = 0;
 #pragma clang loop unroll(disable)
     for (int ti = 0; ti < c.n_tiles; ++ti) {
-        const bool refresh = (ti < 3) || (((ti + c.g) & (REFRESH - 1)) == 0);  // uniform over the workgroup
+        const bool refresh = ti > 0 && is_refresh(ti);  // the words loaded at the end of iteration ti-1 are live
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
@@ -1774,21 +1785,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         // front of the next tile's, so they have arrived when the MFMA phase ends
         const int ti_nxt = ti + 1 < c.n_tiles ? ti + 1 : ti;  // the last iteration re-reads its own tile: no branch
         const float inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti_nxt)) * 32 + j];
-        uint32_t mword[RPO], gtau[RPO], gb[RPO][SETS];
+        uint32_t mword[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
             const bool qok = (o.okmask >> e) & 1u;
             const uint32_t *mp = p.mask ? p.mask + (size_t)(qok ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile : no_mask;
             const uint32_t mv = *mp;
             mword[e] = p.mask ? mv : 0xffffffffu;
-            const bool live = refresh && qok;
-            const uint32_t *tp = live ? tau_ptr + e * PF_BOUND_CELLS : idle_row;
-            gtau[e] = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int s = 0; s < SETS; ++s) {
-                const uint32_t *gp = live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row;
-                gb[e][s] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
 
         f32x16 acc[NQB];
@@ -1829,9 +1832,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) sc[e] += v[e];
         }
         buf ^= 1;
+        if (refresh) {  // the idle record reads 0: nothing to merge on the other tiles
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) tau[e] = gtau[e] > tau[e] ? gtau[e] : tau[e];  // the idle record reads 0
-        if (refresh) derive(gb);
+            for (int e = 0; e < RPO; ++e)
+                if (j == 0 && gtau[e] > tau[e]) tau[e] = gtau[e];
+            derive(gb);
+        }
         const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
         const int set = (int)(tile & (int64_t)(SETS - 1));
         bool pass[RPO];
@@ -1844,11 +1850,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             // such rows (the candidates, a few dozen per query and search) are published.  While no bound exists
             // everything qualifies: then one workgroup in eight (another eighth on every tile) publishes a class,
             // which fills every class 32 times over instead of 256 (an atomic storm on 32 cells per query otherwise).
-            const bool lift = tau[e] != 0u ? (ord > tau[e]) : (ord != 0u && (((c.g + j + ti) & 7) == 0));
+            const uint32_t te = tau[e];
+            const bool lift = te != 0u ? (ord > te) : (ord != 0u && (((c.g + j + ti) & 7) == 0));
             if (lift)
                 (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
-            pass[e] = prev[e] >= threshold(tau[e]);  // the PREVIOUS tile against the bound known now
+            pass[e] = prev[e] >= threshold(te);  // the PREVIOUS tile against the bound known now
         }
         if (ti > 1) pf_stage<NQB>(L, o, prev, pass, row_in_window(ti - 1), p.flags);
         if (ti == 0) {
@@ -1859,15 +1866,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) prev[e] = sc[e];
         }
         inv_cur = inv_nxt;
+        {   // bound words for the next iteration (to the idle record unless it is a refresh tile)
+            const bool next_live = is_refresh(ti + 1);
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) {
+                const bool live = next_live && ((o.okmask >> e) & 1u);
+                const uint32_t *tp = live ? tau_ptr + e * PF_BOUND_CELLS : idle_row;
+                gtau[e] = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int s = 0; s < SETS; ++s) {
+                    const uint32_t *gp = live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row;
+                    gb[e][s] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
     if (c.n_tiles > 0) {  // the last tile and the first one against the final bounds
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        uint32_t gb[RPO][SETS];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
             const bool qok = (o.okmask >> e) & 1u;
             const uint32_t gt = __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tau[e] = (qok && gt > tau[e]) ? gt : tau[e];
+            if (j == 0 && qok && gt > tau[e]) tau[e] = gt;
 #pragma unroll
             for (int s = 0; s < SETS; ++s) {
                 const uint32_t v = __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
