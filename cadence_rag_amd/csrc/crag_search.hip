@@ -1745,9 +1745,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // with its own copy.  [Reading them on every tile made 256 workgroups hit the same 64 cache lines at once;
     // the requests serialise per line (~25 ns each), loads return in order, and the corpus stream behind them
     // waited: 6.9 us per tile instead of 5.3.]
-    // The load INSTRUCTIONS are issued on every tile all the same, on the other tiles to the idle record (zeros, a
-    // line no other workgroup reads): a load under a branch would make the number of outstanding loads
-    // path-dependent, and the compiler then waits for far more than it needs at every use of the corpus ring.
+    // (Device-coherent loads bypass the caches: issued on every tile, even to a line nobody else touches, they
+    // are 16 000 scattered DRAM reads per tile time in the middle of the corpus stream.)
     constexpr int REFRESH = 4 * SETS;
     auto derive = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
@@ -1763,9 +1762,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     auto row_in_window = [&](int ti) { return (uint32_t)(tile_of(c, ti) * 32 + j); };
     const uint32_t *const no_mask = reinterpret_cast<const uint32_t *>(p.qinv);  // any cold readable word
 
-    // The bound words are loaded at the END of an iteration and used in the epilogue of the next one: they then sit
-    // behind the next tile's corpus loads in the (in-order) return queue and can never hold corpus data back,
-    // whatever their latency; a whole MFMA phase later they have arrived.
+    // The bound words are loaded at the END of the iteration before a refresh tile and used in that tile's epilogue:
+    // they then sit behind the tile's corpus loads in the (in-order) return queue and can never hold corpus data
+    // back, whatever their latency; a whole MFMA phase later they have arrived.  Being the only loads under a
+    // branch, they make the compiler's count of outstanding loads conservative by their number, which only asks
+    // the MFMA phase of a refresh tile for corpus fragments it is about to need anyway.
     auto is_refresh = [&](int ti) { return (ti < 4) || (((ti + c.g) & (REFRESH - 1)) == 0); };  // uniform over the workgroup
     uint32_t gtau[RPO], gb[RPO][SETS];
 #pragma unroll
@@ -1866,11 +1867,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) prev[e] = sc[e];
         }
         inv_cur = inv_nxt;
-        {   // bound words for the next iteration (to the idle record unless it is a refresh tile)
-            const bool next_live = is_refresh(ti + 1);
+        if (is_refresh(ti + 1)) {  // bound words for the next iteration, only if it is a refresh tile
 #pragma unroll
             for (int e = 0; e < RPO; ++e) {
-                const bool live = next_live && ((o.okmask >> e) & 1u);
+                // a padded / zero query reads the idle record (zeros): no branch per query around the loads
+                const bool live = (o.okmask >> e) & 1u;
                 const uint32_t *tp = live ? tau_ptr + e * PF_BOUND_CELLS : idle_row;
                 gtau[e] = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
