@@ -1760,7 +1760,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     };
     auto threshold = [&](uint32_t t) { return t == 0u ? -__builtin_inff() : ord2f(t) - 2.f * PF_DELTA; };
     auto row_in_window = [&](int ti) { return (uint32_t)(tile_of(c, ti) * 32 + j); };
-    const uint32_t *const no_mask = reinterpret_cast<const uint32_t *>(p.qinv);  // any cold readable word
 
     // The bound words are loaded at the END of the iteration before a refresh tile and used in that tile's epilogue:
     // they then sit behind the tile's corpus loads in the (in-order) return queue and can never hold corpus data
@@ -1768,10 +1767,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // branch, they make the compiler's count of outstanding loads conservative by their number, which only asks
     // the MFMA phase of a refresh tile for corpus fragments it is about to need anyway.
     auto is_refresh = [&](int ti) { return (ti < 4) || (((ti + c.g) & (REFRESH - 1)) == 0); };  // uniform over the workgroup
-    uint32_t gtau[RPO], gb[RPO][SETS];
+    uint32_t gtau[RPO], gb[RPO][SETS], mword[RPO];
 #pragma unroll
     for (int e = 0; e < RPO; ++e) {
         gtau[e] = 0u;
+        mword[e] = 0xffffffffu;
+        if (p.mask && c.n_tiles > 0)
+            mword[e] = p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + c.t_begin + tile_of(c, 0)];
 #pragma unroll
         for (int s = 0; s < SETS; ++s) gb[e][s] = 0u;
     }
@@ -1782,18 +1784,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
-        // operands of this tile's epilogue: issued behind the B loads of this tile (already in flight) and in
-        // front of the next tile's, so they have arrived when the MFMA phase ends
-        const int ti_nxt = ti + 1 < c.n_tiles ? ti + 1 : ti;  // the last iteration re-reads its own tile: no branch
-        const float inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti_nxt)) * 32 + j];
-        uint32_t mword[RPO];
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) {
-            const bool qok = (o.okmask >> e) & 1u;
-            const uint32_t *mp = p.mask ? p.mask + (size_t)(qok ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile : no_mask;
-            const uint32_t mv = *mp;
-            mword[e] = p.mask ? mv : 0xffffffffu;
-        }
+        // The whole tile before the first MFMA: the 16 loads of the next tile then leave back to back, 16 KiB
+        // contiguous per wave and 128 KiB per workgroup.  Consuming the fragments one by one as they arrive
+        // (exact waits) re-issues the loads in dribs and drabs interleaved with 2047 other waves, and the DRAM
+        // pages see it: measured 12 % slower.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
@@ -1866,7 +1861,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
             for (int e = 0; e < RPO; ++e) prev[e] = sc[e];
         }
-        inv_cur = inv_nxt;
+        {   // operands of the next iteration, behind its corpus loads (issued above) in the return queue
+            const int ti_nxt = ti + 1 < c.n_tiles ? ti + 1 : ti;  // the last iteration re-reads its own tile
+            const int64_t tile_nxt = c.t_begin + tile_of(c, ti_nxt);
+            inv_cur = p.inv_norm[tile_nxt * 32 + j];
+            if (p.mask) {
+#pragma unroll
+                for (int e = 0; e < RPO; ++e)
+                    mword[e] = p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile_nxt];
+            }
+        }
         if (is_refresh(ti + 1)) {  // bound words for the next iteration, only if it is a refresh tile
 #pragma unroll
             for (int e = 0; e < RPO; ++e) {
