@@ -1664,8 +1664,198 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
 }
 
 // ---- K1: the fp16 scan.  Grid (G, passes); one pass = 32*NQB queries against this workgroup's row range ------
-template <int NQB, int SETS>
+// ---- K1, k <= 24 (one class set): the fp16 scan.  Grid (G, passes); one pass = 32*NQB queries against this
+// workgroup's row range.  Every tile: the 32 class maxima of each owned query are loaded (issued in front of the
+// next tile's corpus loads, used after the MFMA phase), sorted across the half-wave, the k-th largest is the
+// bound; a row that beats its class maximum publishes it (atomic max).  Measured against the variant below that
+// derives bounds on every fourth tile only and shares them through a word per query (same box, 64 queries):
+// 100 us vs 126 us at 100 000 rows, 683 us vs 769 us at 1M -- the bookkeeping of the shared bound (its
+// device-coherent loads and atomics sit in the same in-order queue as the corpus stream) costs more than four
+// 15-stage sorts per tile.  For k > 24 (two or four class sets, 8-16 sorts per tile) the balance tips.
+template <int NQB>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
+    constexpr int RPO = 2 * NQB, SETS = 1;
+    __shared__ PfLds<NQB> L;
+    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
+    {   // whole tiles per workgroup (see prefilter_refresh_kernel)
+        const int64_t nt = (p.n_rows + 31) >> 5;
+        c.t_begin = (nt * c.g) / p.G;
+        const int64_t t_end = (nt * (c.g + 1)) / p.G;
+        c.n_tiles = (int)(t_end - c.t_begin);
+        c.r_begin = c.t_begin * 32;
+        c.r_end = t_end * 32 < p.n_rows ? t_end * 32 : p.n_rows;
+    }
+    const int lane = c.lane, w = c.w, j = c.j, h = c.h;
+
+    PfOwner<NQB> o;
+    {
+        const int R = w * RPO, qb = R >> 4, r = R & 15;
+        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
+        o.okmask = 0u;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            if (o.qg0 + e < p.nq && p.qinv[o.qg0 + e] > 0.f) o.okmask |= 1u << e;
+    }
+    if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) L.n_stage = 0u;
+
+    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
+    u32x4 b[16];
+    {
+        const uint32_t v0 = tile_voff(c, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+    }
+    // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
+    // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
+    f16x8 a[NQB][8];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) {
+        const f16x8 *af = reinterpret_cast<const f16x8 *>(p.a16) +
+                          ((size_t)(((int)blockIdx.y * NQB + qb) * SCAN_WAVES + w) * 8) * 64 + lane;
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
+    }
+    float stash[RPO];  // the first tile's scores (NaN = not eligible): judged at the end, when bounds exist
+#pragma unroll
+    for (int e = 0; e < RPO; ++e) stash[e] = __uint_as_float(0x7fc00000u);
+    uint32_t stash_row = 0u;
+    float inv_cur = 0.f;
+    if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
+    __syncthreads();
+
+    // k_s of set s: the (k_s)-th largest class maximum of the set is reached by k_s distinct rows (SETS <= k)
+    const int k_base = p.k / SETS, k_rem = p.k % SETS;
+    const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
+
+    // class maxima of the owned queries, device-coherent loads (they are updated by every workgroup)
+    auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+#pragma unroll
+            for (int s = 0; s < SETS; ++s)
+                gb[e][s] = ((o.okmask >> e) & 1u)
+                               ? __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0u;
+    };
+    // candidate thresholds of the owned queries: min over the sets of the (k_s)-th largest class maximum, - 2 delta
+    auto thresholds = [&](const uint32_t (&gb)[RPO][SETS], float (&thr)[RPO]) {
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) {
+            uint32_t tau = 0xffffffffu;
+#pragma unroll
+            for (int s = 0; s < SETS; ++s) {
+                const uint32_t sorted = sort32_desc_u32(gb[e][s], lane);
+                const int ks = k_base + (s < k_rem ? 1 : 0);
+                const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
+                tau = kth < tau ? kth : tau;
+            }
+            thr[e] = tau == 0u ? -__builtin_inff() : ord2f(tau) - 2.f * PF_DELTA;
+        }
+    };
+
+    int buf = 0;
+    for (int ti = 0; ti < c.n_tiles; ++ti) {
+        const uint32_t vnext = tile_voff(c, ti + 1);
+        const int64_t tile = c.t_begin + tile_of(c, ti);
+        const int64_t row = tile * 32 + j;
+        // operands of this tile's epilogue: issued behind the B loads of this tile (already in flight) and in
+        // front of the next tile's, so they have arrived when the MFMA phase ends
+        float inv_nxt = 0.f;
+        if (ti + 1 < c.n_tiles) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1)) * 32 + j];
+        uint32_t mword[RPO], gb[RPO][SETS];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
+                              : 0xffffffffu;
+        load_bounds(gb);
+
+        f32x16 acc[NQB];
+        static_for<0, 8>([&](auto T) {
+            constexpr int t8 = decltype(T)::value;
+            // two loads = dims {16 t8 + 4h + 0..3} and {16 t8 + 8 + 4h + 0..3} of row j: normalise, round to fp16
+            const f32x4 lo = __builtin_bit_cast(f32x4, b[2 * t8]) * inv_cur;
+            const f32x4 hi = __builtin_bit_cast(f32x4, b[2 * t8 + 1]) * inv_cur;
+            const f16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), f16x2);
+            const f16x2 p1 = __builtin_convertvector((f32x2{lo[2], lo[3]}), f16x2);
+            const f16x2 p2 = __builtin_convertvector((f32x2{hi[0], hi[1]}), f16x2);
+            const f16x2 p3 = __builtin_convertvector((f32x2{hi[2], hi[3]}), f16x2);
+            const f16x8 bf = f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qb][t8], bf, t8 == 0 ? zero16 : acc[qb], 0, 0, 0);
+            b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8) * 1024, 0, 0);
+            b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // split-K: owner wave ow gets registers [ow*RPO, ow*RPO+RPO) of every producer
+#pragma unroll
+        for (int ow = 0; ow < SCAN_WAVES; ++ow) {
+            typename PfLds<NQB>::slab_t v;
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) v[e] = acc[(ow * RPO + e) >> 4][(ow * RPO + e) & 15];
+            L.slab[buf][ow][w][lane] = v;
+        }
+        // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        float sc[RPO], thr[RPO];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SCAN_WAVES; ++ww) {
+            const typename PfLds<NQB>::slab_t v = L.slab[buf][w][ww][lane];
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) sc[e] += v[e];
+        }
+        buf ^= 1;
+        thresholds(gb, thr);
+        const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
+        const int set = (int)(tile & (int64_t)(SETS - 1));
+        bool pass[RPO];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) {
+            const bool ok = row_ok && ((o.okmask >> e) & 1u) && ((mword[e] >> j) & 1u) && (sc[e] == sc[e]);
+            sc[e] = ok ? sc[e] : __uint_as_float(0x7fc00000u);
+            // publish an improved class maximum (rare: only a row that beats everything seen in its class)
+            uint32_t seen = gb[e][0];
+#pragma unroll
+            for (int s = 1; s < SETS; ++s) seen = (s == set) ? gb[e][s] : seen;
+            if (ok && f2ord(sc[e]) > seen)
+                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, f2ord(sc[e]), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+            pass[e] = sc[e] >= thr[e];
+        }
+        if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
+            stash_row = (uint32_t)(row - c.t_begin * 32);
+        } else {
+            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
+        }
+        inv_cur = inv_nxt;
+    }
+    if (c.n_tiles > 0) {  // the first tile against the final bounds
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        uint32_t gb[RPO][SETS];
+        float thr[RPO];
+        load_bounds(gb);
+        thresholds(gb, thr);
+        bool pass[RPO];
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
+        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
+    }
+    pf_flush<NQB>(p, L, c.t_begin * 32);
+}
+
+// ---- K1, k > 24 (two or four class sets): bounds derived on refresh tiles only and shared through a word per query --
+template <int NQB, int SETS>
+__global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB;
     __shared__ PfLds<NQB> L;
     // row range of this workgroup: whole tiles (a partial tile costs a full trip through the loop here, where a
@@ -2166,13 +2356,13 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, p);     \
     } while (0)
     if (nqb == 2) {
-        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<2, 1>);
-        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<2, 2>);
-        else CRAG_LAUNCH(prefilter_kernel<2, 4>);
+        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<2>);
+        else if (p.sets == 2) CRAG_LAUNCH(prefilter_refresh_kernel<2, 2>);
+        else CRAG_LAUNCH(prefilter_refresh_kernel<2, 4>);
     } else {
-        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<1, 1>);
-        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<1, 2>);
-        else CRAG_LAUNCH(prefilter_kernel<1, 4>);
+        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<1>);
+        else if (p.sets == 2) CRAG_LAUNCH(prefilter_refresh_kernel<1, 2>);
+        else CRAG_LAUNCH(prefilter_refresh_kernel<1, 4>);
     }
 #undef CRAG_LAUNCH
     if (kernel_name) *kernel_name = name;
