@@ -2119,18 +2119,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
 constexpr int FIN_ROUND = 2048;             // candidates examined per round
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
-__device__ __forceinline__ float exact_slice_dot(const f32x4 *afrag /* + sub*16*64 + (h*32+i) applied by caller */,
-                                                 const f32x4 *ctile /* tile base + sub slice */, int jrow) {
-    // slice `sub` of the 1024 dims: s = 0..15, then component, then lane half (k = 0, 1 of one 32x32x2 MFMA)
-    float acc = 0.f;
-#pragma unroll 4
+// One 128-dim slice of the exact dot product: the query slice comes from LDS (fragment order), the row's 32
+// float4 are fetched first, all of them (32 independent 16-byte loads in flight: the row is scattered over 256
+// cache lines in the tile32 layout, latency is everything here), then the fmaf chain runs in the scan's k order:
+// s = 0..15, then component, then lane half (k = 0, 1 of one 32x32x2 MFMA).
+__device__ __forceinline__ float exact_slice_dot(const f32x4 *qslice /* [16][2] float4 in LDS */,
+                                                 const f32x4 *ctile /* tile base + slice */, int jrow) {
+    f32x4 c0[16], c1[16];
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const f32x4 q0 = afrag[(s * 64)], q1 = afrag[(s * 64) + 32];
-        const f32x4 c0 = ctile[(2 * s) * 32 + jrow], c1 = ctile[(2 * s + 1) * 32 + jrow];
+        c0[s] = ctile[(2 * s) * 32 + jrow];
+        c1[s] = ctile[(2 * s + 1) * 32 + jrow];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const f32x4 q0 = qslice[2 * s], q1 = qslice[2 * s + 1];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            acc = __builtin_fmaf(q0[cc], c0[cc], acc);
-            acc = __builtin_fmaf(q1[cc], c1[cc], acc);
+            acc = __builtin_fmaf(q0[cc], c0[s][cc], acc);
+            acc = __builtin_fmaf(q1[cc], c1[s][cc], acc);
         }
     }
     return acc;
@@ -2140,6 +2148,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     __shared__ uint64_t best[FIN_BEST];
     __shared__ uint2 lcand[FIN_ROUND];     // the candidates of the common case (all of them fit): x = score, y = row
     __shared__ uint32_t surv[FIN_ROUND];   // rows to rescore in the current round
+    __shared__ f32x4 qs[SCAN_WAVES][16][2];  // the query in fragment order: [slice][s][lane half]
     __shared__ int hist[256];
     __shared__ int wave_tot[MERGE_THREADS / 64];
     __shared__ int s_digit, s_need, s_nbest, s_nsurv, s_rescored;
@@ -2156,6 +2165,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     const bool in_lds = C <= FIN_ROUND;
     if (in_lds)
         for (int e = tid; e < C; e += MERGE_THREADS) lcand[e] = gcand[e];
+    {   // thread t = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
+        const int w8 = tid >> 5, s16 = (tid >> 1) & 15, h2 = tid & 1;
+        qs[w8][s16][h2] = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + w8) * 16 + s16) * 64 + h2 * 32 + (q & 31)];
+    }
     if (tid == 0) {
         s_nbest = 0;
         s_rescored = 0;
@@ -2211,9 +2224,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
 
     // 2. survivors -> exact scores, 8 lanes per row, in rounds of FIN_ROUND candidates
     const int grp = tid >> 3, sub = tid & 7;  // 32 rows per sweep; lane `sub` = K slice (the scan's wave w)
-    const int qb = q >> 5, qi = q & 31;
     const float qinv = p.qinv[q];
-    const f32x4 *afrag = reinterpret_cast<const f32x4 *>(p.a32) + ((size_t)(qb * SCAN_WAVES + sub) * 16) * 64 + qi;
     for (int r0 = 0; r0 < C; r0 += FIN_ROUND) {
         const int rn = (C - r0) < FIN_ROUND ? (C - r0) : FIN_ROUND;
         if (tid == 0) s_nsurv = 0;
@@ -2231,7 +2242,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
             float part = 0.f;
             if (live) {
                 const f32x4 *ctile = reinterpret_cast<const f32x4 *>(p.corpus + (size_t)(row >> 5) * TILE_FLOATS) + (size_t)sub * 32 * 32;
-                part = exact_slice_dot(afrag, ctile, (int)(row & 31u));
+                part = exact_slice_dot(&qs[sub][0][0], ctile, (int)(row & 31u));
             }
             // the 8 slice sums in wave order 0..7 (the scan kernels' split-K reduction order)
             float d = __shfl(part, (tid & 63 & ~7) | 0);

@@ -387,6 +387,7 @@ def test_backfill_through_native_encoder_into_hbm_index(gpu, monkeypatch):
 
     def chunk_columns(ids):
         return {"chunk_id": list(ids), "call_id": [tables["chunks"][i]["call_id"] for i in ids],
+                "speaker": ["S"] * len(ids), "start_ts_ms": [0] * len(ids), "end_ts_ms": [1] * len(ids),
                 "text": [tables["chunks"][i]["text"] for i in ids]}
 
     store = ep.InMemoryStore(tables, sinks={"chunks": chunk_table.sink(chunk_columns), "artifact_chunks": art_index})
