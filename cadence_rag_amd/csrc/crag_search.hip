@@ -2149,9 +2149,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     __shared__ uint2 lcand[FIN_ROUND];     // the candidates of the common case (all of them fit): x = score, y = row
     __shared__ uint32_t surv[FIN_ROUND];   // rows to rescore in the current round
     __shared__ f32x4 qs[SCAN_WAVES][16][2];  // the query in fragment order: [slice][s][lane half]
-    __shared__ int hist[256];
-    __shared__ int wave_tot[MERGE_THREADS / 64];
-    __shared__ int s_digit, s_need, s_nbest, s_nsurv, s_rescored;
+    __shared__ int64_t best_id[FIN_BEST];  // external id of best[i]'s row, fetched beside the row itself
+    __shared__ int hist[32];               // exchange buffer of the workgroup reductions
+    __shared__ int s_nbest, s_nsurv, s_rescored;
     __shared__ uint32_t s_kth;
     const int q = blockIdx.x, tid = threadIdx.x;
     if (p.flags[0] != 0u) {  // uniform over the grid
@@ -2179,44 +2179,82 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     // 1. k-th largest approximate score among the candidates
     uint32_t thr_ord = 0u;
     if (C > k) {
-        if (C <= 2 * MERGE_THREADS) {  // the usual case (a few dozen candidates): rank by counting, one barrier
-            for (int e = tid; e < C; e += MERGE_THREADS) {
-                const uint32_t mine = lcand[e].x;
+        if (C <= MERGE_THREADS) {  // the usual case for k <= 24 (a few dozen candidates): rank by counting, one barrier
+            if (tid < C) {
+                const uint32_t mine = lcand[tid].x;
                 int rank = 0;
                 for (int i = 0; i < C; ++i) {
                     const uint32_t o = lcand[i].x;
-                    rank += (o > mine || (o == mine && i < e)) ? 1 : 0;
+                    rank += (o > mine || (o == mine && i < tid)) ? 1 : 0;
                 }
                 if (rank == k - 1) s_kth = mine;
             }
             __syncthreads();
-        } else {  // radix select over the 32-bit orderable scores, 4 x 8 bits
-            uint32_t prefix = 0u, pmask = 0u;
-            int need = k;
-            for (int pass = 0; pass < 4; ++pass) {
-                const int shift = 24 - 8 * pass;
-                hist[tid] = 0;
-                __syncthreads();
-                for (int e = tid; e < C; e += MERGE_THREADS) {
-                    const uint32_t o = in_lds ? lcand[e].x : gcand[e].x;
-                    if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1);
-                }
-                __syncthreads();
-                {
-                    const int above = suffix_above(hist, wave_tot, tid);
-                    const int here = hist[tid];
-                    if (above < need && above + here >= need) {
-                        s_digit = tid;
-                        s_need = need - above;
-                    }
-                }
-                __syncthreads();
-                prefix |= (uint32_t)s_digit << shift;
-                pmask |= 255u << shift;
-                need = s_need;
-                __syncthreads();
+        } else {
+            // Binary search on the orderable score: the largest T with at least k candidates >= T, one bit per
+            // round, counting in registers (each thread keeps its <= 8 candidates; beyond FIN_ROUND candidates it
+            // re-reads them) + a wave reduction + one barrier.  The candidates sit just above a common threshold,
+            // so their high bits agree: the search starts below the highest bit in which any two of them differ.
+            // (A radix select with an LDS histogram serialises here: a thousand atomics on ONE bin per pass.)
+            constexpr int PER = FIN_ROUND / MERGE_THREADS;
+            uint32_t v[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int e = tid + i * MERGE_THREADS;
+                v[i] = (in_lds && e < C) ? lcand[e].x : 0u;
             }
-            if (tid == 0) s_kth = prefix;
+            auto block_sum = [&](int x, int round) {  // sum over the workgroup; hist[] doubles as the exchange buffer
+                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+                int *slot = hist + (round & 1) * 8;
+                if ((tid & 63) == 0) slot[tid >> 6] = x;
+                __syncthreads();
+                return slot[0] + slot[1] + slot[2] + slot[3];
+            };
+            uint32_t vmax = 0u, vmin = 0xffffffffu;
+            if (in_lds) {
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    if (tid + i * MERGE_THREADS < C) {
+                        vmax = v[i] > vmax ? v[i] : vmax;
+                        vmin = v[i] < vmin ? v[i] : vmin;
+                    }
+            } else {
+                for (int e = tid; e < C; e += MERGE_THREADS) {
+                    const uint32_t o = gcand[e].x;
+                    vmax = o > vmax ? o : vmax;
+                    vmin = o < vmin ? o : vmin;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t a = (uint32_t)__shfl_xor((int)vmax, o), b = (uint32_t)__shfl_xor((int)vmin, o);
+                vmax = a > vmax ? a : vmax;
+                vmin = b < vmin ? b : vmin;
+            }
+            if ((tid & 63) == 0) {
+                hist[16 + (tid >> 6)] = (int)vmax;
+                hist[20 + (tid >> 6)] = (int)vmin;
+            }
+            __syncthreads();
+            for (int i = 0; i < MERGE_THREADS / 64; ++i) {
+                const uint32_t a = (uint32_t)hist[16 + i], b = (uint32_t)hist[20 + i];
+                vmax = a > vmax ? a : vmax;
+                vmin = b < vmin ? b : vmin;
+            }
+            const uint32_t diff = vmax ^ vmin;
+            const int top = diff ? 32 - __builtin_clz(diff) : 0;       // bits [top, 32) are common to all candidates
+            uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
+            for (int bit = top - 1; bit >= 0; --bit) {
+                const uint32_t trial = ans | (1u << bit);
+                int cnt = 0;
+                if (in_lds) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) cnt += v[i] >= trial ? 1 : 0;
+                } else {
+                    for (int e = tid; e < C; e += MERGE_THREADS) cnt += gcand[e].x >= trial ? 1 : 0;
+                }
+                if (block_sum(cnt, bit) >= k) ans = trial;
+            }
+            if (tid == 0) s_kth = ans;
             __syncthreads();
         }
         thr_ord = f2ord(ord2f(s_kth) - 2.f * PF_DELTA);
@@ -2239,8 +2277,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
             const int e = e0 + grp;
             const bool live = e < ns;
             const uint32_t row = live ? surv[e] : 0u;
-            float part = 0.f;
+            float part = 0.f, inv_row = 0.f;
+            int64_t rid = -1;
             if (live) {
+                if (sub == 0) {  // in flight together with the row's own loads
+                    inv_row = p.inv_norm[row];
+                    rid = p.ids ? p.ids[row] : (int64_t)row;
+                }
                 const f32x4 *ctile = reinterpret_cast<const f32x4 *>(p.corpus + (size_t)(row >> 5) * TILE_FLOATS) + (size_t)sub * 32 * 32;
                 part = exact_slice_dot(&qs[sub][0][0], ctile, (int)(row & 31u));
             }
@@ -2249,13 +2292,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww) d += __shfl(part, (tid & 63 & ~7) | ww);
             if (live && sub == 0) {
-                const float scale = p.inv_norm[row] * qinv;
+                const float scale = inv_row * qinv;
                 float sc = d * scale;
                 sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);
                 if (scale > 0.f && sc == sc) {
                     const uint32_t u = __float_as_uint(sc);
                     const uint32_t ord = u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
-                    best[atomicAdd(&s_nbest, 1)] = mk64(ord, ~row);
+                    const int slot = atomicAdd(&s_nbest, 1);
+                    best[slot] = mk64(ord, ~row);
+                    best_id[slot] = rid;
                 }
             }
         }
@@ -2264,6 +2309,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
         if (r0 + FIN_ROUND < C && s_nbest > k) {  // more rounds follow: keep only the running top-k
             const int B = s_nbest;
             uint64_t mine[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
+            int64_t mine_id[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
             int rank[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
             int n_mine = 0;
             for (int e = tid; e < B; e += MERGE_THREADS) {
@@ -2271,11 +2317,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
                 int rk = 0;
                 for (int i = 0; i < B; ++i) rk += (best[i] > m) ? 1 : 0;
                 mine[n_mine] = m;
+                mine_id[n_mine] = best_id[e];
                 rank[n_mine++] = rk;
             }
             __syncthreads();
             for (int e = 0; e < n_mine; ++e)
-                if (rank[e] < k) best[rank[e]] = mine[e];
+                if (rank[e] < k) {
+                    best[rank[e]] = mine[e];
+                    best_id[rank[e]] = mine_id[e];
+                }
             if (tid == 0) s_nbest = k;
             __syncthreads();
         }
@@ -2289,9 +2339,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
         int rank = 0;
         for (int i = 0; i < B; ++i) rank += (best[i] > mine) ? 1 : 0;
         if (rank < k) {
-            const uint32_t row = ~(uint32_t)(mine & 0xffffffffull);
             p.out_scores[(size_t)q * k + rank] = ord2f((uint32_t)(mine >> 32));
-            p.out_ids[(size_t)q * k + rank] = p.ids ? p.ids[row] : (int64_t)row;
+            p.out_ids[(size_t)q * k + rank] = best_id[e];
         }
     }
     for (int r = count + tid; r < k; r += MERGE_THREADS) {
