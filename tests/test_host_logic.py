@@ -433,3 +433,99 @@ def test_retrieve_evidence_needs_a_backend():
     retrieve.set_backend(None)
     with pytest.raises(RuntimeError, match="no backend"):
         retrieve.retrieve_evidence(retrieve.RetrieveRequest(query="x"))
+
+
+# ---- device-resident backfill path (embed_texts_device / DeviceSinkStore): same guards, no float lists --------
+class _FakeDeviceEncoder:
+    """encode_device protocol with CPU tensors (the contract is 'a float32 [n, dim] tensor', wherever it lives)."""
+
+    def __init__(self, dim=1024, limit=None):
+        self.dim, self.limit, self.calls = dim, limit, []
+
+    def encode_device(self, texts):
+        import torch
+        self.calls.append(len(texts))
+        if self.limit is not None and len(texts) > self.limit:
+            raise RuntimeError(f"batch-size must be <= {self.limit}")
+        v = torch.arange(len(texts) * self.dim, dtype=torch.float32).reshape(len(texts), self.dim)
+        return v, "fake-model"
+
+    def encode(self, texts):
+        raise AssertionError("the list-returning form must not be used on the device path")
+
+
+def test_embed_texts_device_guards_and_shapes(monkeypatch):
+    from cadence_rag_amd import embeddings
+    monkeypatch.setattr(embeddings.settings, "embeddings_base_url", "")
+    with pytest.raises(EmbeddingClientError, match="EMBEDDINGS_BASE_URL is not configured"):
+        embeddings.embed_texts_device(["x"])
+    monkeypatch.setattr(embeddings.settings, "embeddings_base_url", "http://gateway:8000")
+    with pytest.raises(EmbeddingClientError, match="need the native encoder"):
+        embeddings.embed_texts_device(["x"])
+    monkeypatch.setattr(embeddings.settings, "embeddings_base_url", "native")
+    monkeypatch.setattr(embeddings.settings, "embeddings_dim", 1024)
+    embeddings.set_encoder(_FakeDeviceEncoder())
+    try:
+        with pytest.raises(EmbeddingClientError, match="at least one non-empty text"):
+            embeddings.embed_texts_device(["", "  "])
+        res = embeddings.embed_texts_device([" a ", "", "b"])
+        assert tuple(res.vectors.shape) == (2, 1024) and res.model == "fake-model"
+        embeddings.set_encoder(_FakeDeviceEncoder(dim=512))
+        with pytest.raises(EmbeddingClientError, match="embedding 0 has dim 512; expected 1024"):
+            embeddings.embed_texts_device(["a"])
+    finally:
+        embeddings.set_encoder(None)
+
+
+def test_device_sink_store_backfill_and_adaptive_downshift(monkeypatch):
+    """run_embedding_backfill over a DeviceSinkStore: tensors go to the sink, rows are marked, and the batch
+    downshift of _embed_texts_adaptive (embedding_pipeline.py:88-118) works on the device path too."""
+    from cadence_rag_amd import embedding_pipeline as ep, embeddings
+    monkeypatch.setattr(embeddings.settings, "embeddings_base_url", "native")
+    monkeypatch.setattr(embeddings.settings, "embeddings_dim", 1024)
+    enc = _FakeDeviceEncoder(limit=2)
+    embeddings.set_encoder(enc)
+
+    class Sink:
+        def __init__(self):
+            self.batches = []
+
+        def add(self, vectors, ids):
+            self.batches.append((tuple(vectors.shape), list(ids)))
+
+    sink = Sink()
+    tables = {"chunks": {i: {"call_id": UUID(int=1), "text": f"t{i}", "embedding": None} for i in range(5)},
+              "artifact_chunks": {}}
+    ep.set_store(ep.DeviceSinkStore(tables, sinks={"chunks": sink}))
+    try:
+        summary = ep.run_embedding_backfill(batch_size=5)
+        assert summary.rows_updated == 5 and summary.per_table == {"chunks": 5, "artifact_chunks": 0}
+        assert enc.calls == [5, 2, 2, 1]                      # the reference's downshift trace
+        assert sink.batches == [((5, 1024), [0, 1, 2, 3, 4])]  # one tensor per fetched batch
+        assert all(r["embedding"] == "hbm" for r in tables["chunks"].values())
+        ep.set_store(ep.DeviceSinkStore({"chunks": {1: {"call_id": UUID(int=1), "text": "x", "embedding": None}},
+                                         "artifact_chunks": {}}, sinks={}))
+        with pytest.raises(RuntimeError, match="no sink"):
+            ep.run_embedding_backfill(batch_size=5)
+    finally:
+        ep.set_store(None)
+        embeddings.set_encoder(None)
+
+
+def test_bench_synthetic_rows_do_not_depend_on_the_shard(monkeypatch):
+    """bench.py defines the synthetic corpus chunk-wise from the seed: a rank that generates rows [lo, hi) gets
+    the rows a single-GPU run sees there (N > 1 shards ONE corpus)."""
+    import importlib.util
+    import sys as _sys
+    from pathlib import Path
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(bench, "SYNTH_CHUNK", 1000)
+    cpu = torch.device("cpu")
+    whole = bench.synth_rows(0, 3500, 7, cpu)
+    assert torch.equal(bench.synth_rows(900, 2100, 7, cpu), whole[900:2100])
+    assert torch.equal(bench.synth_rows(3000, 3500, 7, cpu), whole[3000:3500])
+    assert torch.allclose(whole.norm(dim=1), torch.ones(3500), atol=1e-5)
+    assert not torch.equal(bench.synth_rows(0, 10, 8, cpu), whole[:10])
