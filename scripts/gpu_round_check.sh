@@ -1,29 +1,34 @@
+# Regenerates everything kept under profiles/ for this round (run on the GPU box through gpurun):
+#   kernel-trace stats of the default bench command, FETCH_SIZE / WRITE_SIZE passes (separate runs, as the
+#   microarchitecture guide prescribes) for the three search workloads of the bench line, SQ counters.
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $R/gpurun_out/r01/gpu_tests.log 2>&1
-tail -3 $R/gpurun_out/r01/gpu_tests.log
-python bench.py > $R/gpurun_out/r01/bench.json 2> $R/gpurun_out/r01/bench.err
-cat $R/gpurun_out/r01/bench.json
-python bench.py --queries 32 --no-encode --no-cpu-baseline > $R/gpurun_out/r01/bench_q32.json 2>> $R/gpurun_out/r01/bench.err
-cat $R/gpurun_out/r01/bench_q32.json
+RN=${ROUND:-r02}
+O=$R/gpurun_out/$RN
+mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01/stats -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/r01/stats_bench.json 2>$R/gpurun_out/r01/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r01/pmc_fetch64 -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-encode > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r01/pmc_write64 -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-encode > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r01/pmc_fetch32 -- python3 $R/bench.py --queries 32 --steps 100 --warmup 10 --no-cpu-baseline --no-encode > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r01/pmc_write32 -- python3 $R/bench.py --queries 32 --steps 100 --warmup 10 --no-cpu-baseline --no-encode > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
+B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64 -- python3 $R/bench.py $B > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m64 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 64 --steps 60 > /dev/null 2>&1
+done
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $O/pmc_sq_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
 cd $R
-for t in fetch64 write64 fetch32 write32; do python scripts/pmc_summary.py pmc gpurun_out/r01/pmc_$t gpurun_out/r01/pmc_${t}_summary.csv; done
-python scripts/pmc_summary.py stats gpurun_out/r01/stats gpurun_out/r01/kernel_stats.csv
+python scripts/pmc_summary.py stats $O/stats $O/${RN}_bench_kernel_stats.csv
+for w in 100k64 1m32 1m64; do
+  for c in FETCH_SIZE WRITE_SIZE; do python scripts/pmc_summary.py pmc $O/pmc_${c}_$w $O/${RN}_pmc_${c}_$w.csv; done
+done
+python scripts/pmc_summary.py pmc $O/pmc_sq_1m32 $O/${RN}_prefilter_1m_q32_sq_counters.csv
+python scripts/pmc_summary.py pmc $O/pmc_sq2_1m32 $O/${RN}_prefilter_1m_q32_sq_counters2.csv
+python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_100k64.csv $O/${RN}_pmc_WRITE_SIZE_100k64.csv 100000x64x10 $O/traffic.json
+python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m32.csv $O/${RN}_pmc_WRITE_SIZE_1m32.csv 1000000x32x10 $O/traffic.json
+python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m64.csv $O/${RN}_pmc_WRITE_SIZE_1m64.csv 1000000x64x10 $O/traffic.json
 # raw traces are large: keep only summaries
-rm -rf gpurun_out/r01/pmc_fetch64 gpurun_out/r01/pmc_write64 gpurun_out/r01/pmc_fetch32 gpurun_out/r01/pmc_write32
-find gpurun_out/r01/stats -name "*kernel_trace.csv" -delete
-head -12 gpurun_out/r01/kernel_stats.csv
-# 1M-row single-GPU lines (north-star target: >= 70 % of the HBM roofline at 1M x 1024)
-python bench.py --rows-per-gpu 1000000 --queries 32 --steps 50 --warmup 5 --no-encode --no-cpu-baseline > gpurun_out/r01/bench_1m_q32.json 2>> gpurun_out/r01/bench.err
-python bench.py --rows-per-gpu 1000000 --queries 64 --steps 50 --warmup 5 --no-encode --no-cpu-baseline > gpurun_out/r01/bench_1m_q64.json 2>> gpurun_out/r01/bench.err
-cat gpurun_out/r01/bench_1m_q32.json gpurun_out/r01/bench_1m_q64.json
-python scripts/hybrid_bench.py > gpurun_out/r01/hybrid.json 2>> gpurun_out/r01/bench.err
-cat gpurun_out/r01/hybrid.json
+rm -rf $O/pmc_* $O/stats
+cat $O/traffic.json
+head -14 $O/${RN}_bench_kernel_stats.csv | cut -c1-160

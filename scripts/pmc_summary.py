@@ -3,7 +3,7 @@
 
   pmc_summary.py pmc   <rocprof_out_dir> <out_csv>        per-kernel mean of every counter collected
   pmc_summary.py stats <rocprof_out_dir> <out_csv>        copy of the *_kernel_stats.csv
-  pmc_summary.py traffic <fetch_csv> <write_csv> <queries_per_step> <traffic.json> <alg_bytes>
+  pmc_summary.py traffic <fetch_csv> <write_csv> <ROWSxQUERIESxK> <traffic.json>
         fold the scan kernel's FETCH_SIZE / WRITE_SIZE means into profiles/traffic.json
         (FETCH_SIZE x2: gfx950 reports half of a wide coalesced streaming read,
          /opt/skills/guides/MI355X_MICROARCH.md HBM section; values are KB -> x1024).
@@ -45,26 +45,39 @@ def stats(root: str, out_csv: str) -> None:
 
 
 def _scan_mean(path: str, counter: str):
+    """(kernel, mean) of `counter` for the dominant scan kernel of a run (the prefilter / scan kernel with the most
+    launches)."""
+    best = None
     with open(path, newline="") as fh:
         for row in csv.DictReader(fh):
-            if row["counter"] == counter and "scan_" in row["kernel"]:
-                val = row.get("avg_value") or row.get("avg_value_KB")
-                return row["kernel"].split("(")[0], float(val)
-    return None, None
+            if row["counter"] != counter:
+                continue
+            name = row["kernel"]
+            if "prefilter_" in name or "scan_pipe" in name:
+                key = (int(row["launches"]), "prefilter_" in name)
+                if best is None or key > best[0]:
+                    best = (key, name, float(row["avg_value"]))
+    return (None, None) if best is None else (best[1], best[2])
 
 
-def traffic(fetch_csv: str, write_csv: str, nq: str, out_json: str, alg_bytes: str) -> None:
+def traffic(fetch_csv: str, write_csv: str, workload: str, out_json: str) -> None:
+    """workload = ROWSxQUERIESxK as bench.py's roofline() keys it."""
     kern, fetch_kb = _scan_mean(fetch_csv, "FETCH_SIZE")
     _, write_kb = _scan_mean(write_csv, "WRITE_SIZE")
     doc = json.load(open(out_json)) if os.path.exists(out_json) else {}
-    doc.setdefault("method", __doc__.strip().splitlines()[-3].strip())
-    doc.setdefault("by_queries_per_step", {})[str(nq)] = {
-        "kernel": kern,
+    doc["method"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                     "`python bench.py --steps .. --no-cpu-baseline --no-encode --no-target-1m [--rows-per-gpu 1000000 "
+                     "--queries 32|64]` (scripts/gpu_round_check.sh); per-kernel means over launches 10.. "
+                     "(scripts/pmc_summary.py); KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half of a wide "
+                     "coalesced streaming read, MI355X_MICROARCH.md HBM section); WRITE_SIZE taken as is.")
+    rows, nq, k = (int(v) for v in workload.split("x"))
+    doc.setdefault("by_workload", {})[workload] = {
+        "kernel": kern.split("(")[0].replace("void ", "").strip(),
         "FETCH_SIZE_KB": fetch_kb,
         "WRITE_SIZE_KB": write_kb,
-        "scan_kernel_hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + (write_kb or 0.0) * 1024),
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + (write_kb or 0.0) * 1024),
+        "algorithmic_bytes_per_launch": rows * 4096 + nq * 4096 + nq * k * 12,
     }
-    doc.setdefault("algorithmic_bytes_per_launch", {})[str(nq)] = int(alg_bytes)
     json.dump(doc, open(out_json, "w"), indent=1)
 
 
