@@ -1676,6 +1676,8 @@ template <int NQB>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB, SETS = 1;
     __shared__ PfLds<NQB> L;
+    const unsigned long long stamp0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long stamp1 = 0ull, stamp2 = 0ull;
     ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
     {   // whole tiles per workgroup (see prefilter_refresh_kernel)
         const int64_t nt = (p.n_rows + 31) >> 5;
@@ -1803,6 +1805,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         }
         // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        if (p.stamps && ti == 0) stamp1 = __builtin_amdgcn_s_memrealtime();
         float sc[RPO], thr[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
@@ -1839,6 +1842,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         }
         inv_cur = inv_nxt;
     }
+    if (p.stamps) stamp2 = __builtin_amdgcn_s_memrealtime();
     if (c.n_tiles > 0) {  // the first tile against the final bounds
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
         uint32_t gb[RPO][SETS];
@@ -1851,6 +1855,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
     }
     pf_flush<NQB>(p, L, c.t_begin * 32);
+    if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) {
+        unsigned long long *o4 = p.stamps + 4 * (size_t)c.g;
+        o4[0] = stamp0;
+        o4[1] = stamp1;
+        o4[2] = stamp2;
+        o4[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- K1, k > 24 (two or four class sets): bounds derived on refresh tiles only and shared through a word per query --

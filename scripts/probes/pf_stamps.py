@@ -1,0 +1,46 @@
+"""Developer probe: where a prefilter scan spends its time (s_memrealtime stamps per workgroup: kernel entry,
+first tile reduced, tile loop done, kernel exit).   CRAG_PF_STAMPS=1 python scripts/probes/pf_stamps.py ROWS NQ"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+os.environ["CRAG_PF_STAMPS"] = "1"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from cadence_rag_amd import _native  # noqa: E402
+from cadence_rag_amd.dense_index import DenseIndex  # noqa: E402
+
+rows, nq = int(sys.argv[1]), int(sys.argv[2])
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(1234)
+ix = DenseIndex(1024, capacity=rows)
+for lo in range(0, rows, 131072):
+    c = torch.randn(min(131072, rows - lo), 1024, generator=g, device=dev)
+    ix.add(c / c.norm(dim=1, keepdim=True))
+q = torch.randn(nq, 1024, generator=g, device=dev)
+oi = torch.empty(nq, 10, dtype=torch.int64, device=dev)
+osc = torch.empty(nq, 10, dtype=torch.float32, device=dev)
+oc = torch.empty(nq, dtype=torch.int32, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+lib = _native.load()
+lib.crag_debug_pf_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+lib.crag_debug_pf_stamps.restype = ctypes.c_int
+G = 256
+acc = []
+for rep in range(40):
+    ix.search_async(q, 10, oi, osc, oc, stream=st)
+    if rep >= 20:
+        buf = np.zeros((G, 4), dtype=np.uint64)
+        assert lib.crag_debug_pf_stamps(ix._h, buf.ctypes.data, G) == 0
+        t = buf.astype(np.int64)
+        t0 = t[:, 0].min()
+        acc.append(np.stack([(t[:, 0] - t0), (t[:, 1] - t0), (t[:, 2] - t0), (t[:, 3] - t0)], axis=1) / 100.0)  # us
+a = np.mean(np.stack(acc), axis=0)
+names = ["entry", "first tile reduced", "tile loop done", "exit"]
+for i, n in enumerate(names):
+    print(f"{n:20s}: min {a[:, i].min():7.2f}  median {np.median(a[:, i]):7.2f}  max {a[:, i].max():7.2f} us after the first workgroup's entry")
+tiles = (rows + 31) // 32
+print(f"tiles per workgroup: {tiles / G:.2f}; per-tile time in the loop (median wg): "
+      f"{np.median((a[:, 2] - a[:, 1])) / max(tiles / G - 1, 1):.2f} us")
