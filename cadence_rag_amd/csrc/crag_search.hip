@@ -568,6 +568,21 @@ __device__ __forceinline__ void pipe_bg(const ScanParams &p, const ScanCtx &c, f
     }
 }
 
+// max over the 32 lanes of each half-wave, result in every lane
+__device__ __forceinline__ uint32_t half_max_u32(uint32_t v) {
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+    v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (16 << 10) | 0x1f);   // lane ^ 16
+    return t > v ? t : v;
+}
+
 // min over the 32 lanes of each half-wave, result in every lane (DPP butterflies + one swizzle)
 __device__ __forceinline__ uint32_t half_min_u32(uint32_t v) {
     uint32_t t;
@@ -1806,6 +1821,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
         if (p.stamps && ti == 0) stamp1 = __builtin_amdgcn_s_memrealtime();
+        if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0 && (c.g & 31) == 0 && ti < 16)
+            p.stamps[1024 + (c.g >> 5) * 16 + ti] = __builtin_amdgcn_s_memrealtime();  // per-tile timeline of 8 workgroups
         float sc[RPO], thr[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
@@ -1828,8 +1845,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             uint32_t seen = gb[e][0];
 #pragma unroll
             for (int s = 1; s < SETS; ++s) seen = (s == set) ? gb[e][s] : seen;
-            if (ok && f2ord(sc[e]) > seen)
-                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, f2ord(sc[e]), __ATOMIC_RELAXED,
+            const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
+            // On the first tile every class is empty and every lane would publish: 524 000 atomics on 2048 cells
+            // from all workgroups at once, and the next tile's bound loads queue up behind them (measured: the
+            // second tile took 17 us instead of 6).  There only the tile's best row per query publishes: the k
+            // best of the 8192 first-tile rows are their tiles' best with high probability, so the bound after
+            // the first tile is as good, from 16 000 atomics.
+            bool lift = ord > seen;
+            if (ti == 0) lift = lift && (ord == half_max_u32(ord));
+            if (lift)
+                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
                                              __HIP_MEMORY_SCOPE_AGENT);
             pass[e] = sc[e] >= thr[e];
         }

@@ -28,19 +28,25 @@ lib = _native.load()
 lib.crag_debug_pf_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 lib.crag_debug_pf_stamps.restype = ctypes.c_int
 G = 256
-acc = []
+acc, tl = [], []
 for rep in range(40):
     ix.search_async(q, 10, oi, osc, oc, stream=st)
     if rep >= 20:
-        buf = np.zeros((G, 4), dtype=np.uint64)
-        assert lib.crag_debug_pf_stamps(ix._h, buf.ctypes.data, G) == 0
+        raw = np.zeros((1024, 4), dtype=np.uint64)
+        assert lib.crag_debug_pf_stamps(ix._h, raw.ctypes.data, 1024) == 0
+        buf = raw[:G]
         t = buf.astype(np.int64)
+        tl.append((raw.reshape(-1)[1024:1024 + 128].astype(np.int64).reshape(8, 16) - t[:, 0].min()) / 100.0)
         t0 = t[:, 0].min()
         acc.append(np.stack([(t[:, 0] - t0), (t[:, 1] - t0), (t[:, 2] - t0), (t[:, 3] - t0)], axis=1) / 100.0)  # us
 a = np.mean(np.stack(acc), axis=0)
 names = ["entry", "first tile reduced", "tile loop done", "exit"]
 for i, n in enumerate(names):
     print(f"{n:20s}: min {a[:, i].min():7.2f}  median {np.median(a[:, i]):7.2f}  max {a[:, i].max():7.2f} us after the first workgroup's entry")
+m = np.mean(np.stack(tl), axis=0)
+print("per-tile timeline (us after entry; reduced tile t) of workgroups 0, 32, ..., 224:")
+for r in m:
+    print("  " + " ".join(f"{v:6.1f}" for v in r))
 tiles = (rows + 31) // 32
 print(f"tiles per workgroup: {tiles / G:.2f}; per-tile time in the loop (median wg): "
       f"{np.median((a[:, 2] - a[:, 1])) / max(tiles / G - 1, 1):.2f} us")
