@@ -119,6 +119,32 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
             "out": (oi, osc, oc)}
 
 
+def overlap_leg(index, queries, k, n_streams, steps):
+    """The same steps issued round-robin on `n_streams` HIP streams: consecutive steps are independent query
+    batches, so the scan of one may run beside the rescoring of another and the memory system never idles between
+    scans.  Throughput only: per-kernel times overlap, the roofline is quoted from the one-stream run."""
+    dev = queries.device
+    nq = int(queries.shape[0])
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    outs = [(torch.empty(nq, k, dtype=torch.int64, device=dev), torch.empty(nq, k, dtype=torch.float32, device=dev),
+             torch.empty(nq, dtype=torch.int32, device=dev)) for _ in range(n_streams)]
+    torch.cuda.synchronize()
+
+    def run(n):
+        for i in range(n):
+            s = i % n_streams
+            index.search_async(queries, k, *outs[s], stream=streams[s].cuda_stream)
+        torch.cuda.synchronize()
+
+    run(max(steps // 10, n_streams))
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    same = all(torch.equal(outs[0][0], o[0]) for o in outs[1:])
+    return {"value": round(nq * steps / dt, 2), "unit": "queries/sec", "ms_per_step": round(dt / steps * 1e3, 5),
+            "steps": steps, "results_identical_across_streams": bool(same)}
+
+
 def roofline(rows, nq, k, leg, traffic_doc):
     """algorithmic bytes = N*D*4 + Q*D*4 + Q*k*12 per launch, / the scan kernel's live event time."""
     alg = rows * DIM * 4 + nq * DIM * 4 + nq * k * 12
@@ -439,6 +465,9 @@ def main() -> None:
         except Exception:
             traffic_doc = None
 
+    overlap = None
+    if world == 1:
+        overlap = {str(n): overlap_leg(index, queries, k, n, args.steps) for n in (2, 3)}
     target = None
     if world == 1 and not args.no_target_1m and rows_total == ROWS_CONFIG1:
         gpu_ids_100k = leg["out"][0].cpu().numpy()
@@ -512,6 +541,8 @@ def main() -> None:
                 "strong scaling of the fixed 1M-row job: the 1-GPU point is `target_1m.q64.value` of the N = 1 line "
                 "(the N = 1 `value` is configs[1], a 100 000-row corpus)" if mode == "strong" else
                 "weak scaling: the corpus grows with N, so a flat `value` is ideal; compare `row_queries_per_s`")
+        if overlap is not None:
+            line["config"]["steps_overlapped_on_streams"] = overlap
         if target is not None:
             line["target_1m"] = target
         if encode is not None:
