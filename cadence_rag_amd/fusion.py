@@ -66,7 +66,10 @@ class TechTokenIndex:
     """GPU-resident `tech_tokens text[]` column + the static order (call_started_at DESC, id ASC).
     Counterpart of _fetch_chunks_tech / _fetch_artifacts_tech (/root/reference/app/retrieve.py:183-242)."""
 
-    def __init__(self, row_tokens, ids, call_started_at, device) -> None:
+    def __init__(self, row_tokens, ids, call_started_at, device, verify: bool = True) -> None:
+        """verify: keep the rows' token strings on the host and check every row the kernel returns against the
+        query's strings.  The kernel compares 64-bit hashes; a collision (2^-64 per comparison) would otherwise be
+        the one way this lane could differ from the SQL `&&`, which compares the strings themselves."""
         n = len(row_tokens)
         ids = np.asarray(ids, dtype=np.int64)
         ts = np.asarray(call_started_at, dtype="datetime64[us]").astype(np.int64)
@@ -85,6 +88,9 @@ class TechTokenIndex:
         self.ids = torch.from_numpy(ids).to(device)
         self._bitmaps: dict = {}   # per stream: two streams sharing one index must not share scratch
         self._rank_of_id = None
+        self._order_host, self._ids_host = order, ids
+        self._row_tokens = [frozenset(t) for t in row_tokens] if verify else None
+        self._pos_of_id = None
 
     def _pass(self, token_lists, k: int, row_mask, mask_stride: int, stream: int):
         """One launch of the lane: at most MAX_QUERY_TOKENS tokens per query."""
@@ -120,7 +126,10 @@ class TechTokenIndex:
         lists = [list(dict.fromkeys(toks)) for toks in query_token_lists]  # distinct, first occurrence kept
         passes = max(1, max((-(-len(t) // MAX_QUERY_TOKENS) for t in lists), default=1))
         if passes == 1:
-            return self._pass(lists, k, row_mask, mask_stride, stream)
+            out_ids, out_ct = self._pass(lists, k, row_mask, mask_stride, stream)
+            if self._row_tokens is not None:
+                out_ids, out_ct = self._verified(lists, k, out_ids, out_ct, row_mask, mask_stride, stream)
+            return out_ids, out_ct
         if self._rank_of_id is None:
             order = self.order.cpu().numpy()
             ids = self.ids.cpu().numpy()
@@ -141,6 +150,39 @@ class TechTokenIndex:
             out_ct[q] = len(best)
         with _on_stream(stream, self.device):
             return torch.from_numpy(out_ids).to(self.device), torch.from_numpy(out_ct).to(self.device)
+
+
+    def _verified(self, lists, k, out_ids, out_ct, row_mask, mask_stride, stream):
+        """String check of the hash matches (one small D2H copy per call).  A false positive — never observed,
+        2^-64 per comparison — is repaired by evaluating that query on the host from the strings."""
+        with _on_stream(stream, self.device):
+            ids_h, ct_h = out_ids.cpu().numpy(), out_ct.cpu().numpy()
+        if self._pos_of_id is None:
+            self._pos_of_id = {int(v): i for i, v in enumerate(self._ids_host)}
+        bad = [q for q, toks in enumerate(lists)
+               if any(self._row_tokens[self._pos_of_id[int(r)]].isdisjoint(toks) for r in ids_h[q, :ct_h[q]])]
+        if not bad:
+            return out_ids, out_ct
+        mask_h = None
+        if row_mask is not None:
+            with _on_stream(stream, self.device):
+                mask_h = row_mask.cpu().numpy().reshape(-1)
+        for q in bad:
+            toks, hits = set(lists[q]), []
+            for pos in self._order_host:
+                if mask_h is not None:
+                    byte = mask_h[(q * mask_stride if mask_stride else 0) + (int(pos) >> 3)]
+                    if not (byte >> (int(pos) & 7)) & 1:
+                        continue
+                if not self._row_tokens[pos].isdisjoint(toks):
+                    hits.append(int(self._ids_host[pos]))
+                    if len(hits) == k:
+                        break
+            ids_h[q] = -1
+            ids_h[q, :len(hits)] = hits
+            ct_h[q] = len(hits)
+        with _on_stream(stream, self.device):
+            return torch.from_numpy(ids_h).to(self.device), torch.from_numpy(ct_h).to(self.device)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -19,7 +19,7 @@ rng = np.random.default_rng(0)
 vocab = [f"TOK-{i}" for i in range(2000)]
 row_tokens = [[vocab[t] for t in rng.integers(0, 2000, size=rng.integers(0, 4))] for _ in range(rows)]
 started = np.datetime64("2026-01-01", "us") + rng.integers(0, 365, size=rows).astype("timedelta64[D]")
-tech = TechTokenIndex(row_tokens, np.arange(rows), started, dev)
+tech = TechTokenIndex(row_tokens, np.arange(rows), started, dev, verify=False)  # batch path: no host round trip
 qtoks = [[vocab[t] for t in rng.integers(0, 2000, size=3)] for _ in range(nq)]
 bm25_ids = torch.from_numpy(rng.integers(0, rows, size=(nq, 50))).to(dev)
 bm25_ct = torch.full((nq,), 50, dtype=torch.int32, device=dev)

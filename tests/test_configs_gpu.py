@@ -267,6 +267,31 @@ def test_tech_lane_with_more_than_32_query_tokens(gpu):
         assert got_ids[qi, :int(got_ct[qi])].tolist() == want
 
 
+def test_tech_lane_hash_collisions_are_repaired_from_the_strings(gpu, monkeypatch):
+    """The kernel matches 64-bit token hashes; TechTokenIndex (verify=True, the default) checks every returned row
+    against the token STRINGS and re-evaluates a query on a mismatch, so the lane has the SQL `&&` semantics
+    exactly.  Forced here with a 2-bit hash."""
+    import torch
+    from cadence_rag_amd import fusion
+    monkeypatch.setattr(fusion, "token_hash", lambda t: 1 + (sum(t.encode()) % 4))
+    rng = np.random.default_rng(13)
+    n = 3000
+    vocab = [f"W{i}" for i in range(50)]
+    row_tokens = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(n)]
+    ids = np.arange(n, dtype=np.int64) + 100
+    started = np.datetime64("2026-05-01", "us") + rng.integers(0, 20, size=n).astype("timedelta64[D]")
+    queries = [["W3"], ["W7", "W8"], [], ["nope"]]
+    order = np.lexsort((ids, -started.astype(np.int64)))
+    want = [[int(ids[p]) for p in order if set(row_tokens[p]) & set(q)][:20] for q in queries]
+    dev = torch.device("cuda", 0)
+    exact = fusion.TechTokenIndex(row_tokens, ids, started, dev)
+    got_ids, got_ct = exact.search(queries, 20)
+    assert [got_ids[i, :int(got_ct[i])].tolist() for i in range(4)] == want
+    loose = fusion.TechTokenIndex(row_tokens, ids, started, dev, verify=False)
+    l_ids, l_ct = loose.search(queries, 20)
+    assert [l_ids[i, :int(l_ct[i])].tolist() for i in range(4)] != want   # the weak hash really collides
+
+
 def test_hybrid_searcher_on_two_side_streams(gpu):
     """HybridSearcher / TechTokenIndex keep their scratch per stream and allocate on the caller's stream: two
     side streams sharing one searcher, launched back to back, give the default-stream answers."""
