@@ -149,8 +149,10 @@ class TechTokenIndex:
             out_ids[q, :len(best)] = best
             out_ct[q] = len(best)
         with _on_stream(stream, self.device):
-            return torch.from_numpy(out_ids).to(self.device), torch.from_numpy(out_ct).to(self.device)
-
+            d_ids, d_ct = torch.from_numpy(out_ids).to(self.device), torch.from_numpy(out_ct).to(self.device)
+        if self._row_tokens is not None:
+            d_ids, d_ct = self._verified(lists, k, d_ids, d_ct, row_mask, mask_stride, stream)
+        return d_ids, d_ct
 
     def _verified(self, lists, k, out_ids, out_ct, row_mask, mask_stride, stream):
         """String check of the hash matches (one small D2H copy per call).  A false positive — never observed,
