@@ -47,6 +47,15 @@ m = np.mean(np.stack(tl), axis=0)
 print("per-tile timeline (us after entry; reduced tile t) of workgroups 0, 32, ..., 224:")
 for r in m:
     print("  " + " ".join(f"{v:6.1f}" for v in r))
+ex = (raw.reshape(-1)[2560:2560 + 4 * G].astype(np.int64).reshape(G, 4) - t[:, 0].min()) / 100.0
+for i, n in enumerate(["loads issued", "first loads landed (vmcnt 0)", "first barrier passed", "first MFMA phase done"]):
+    print(f"{n:30s}: median {np.median(ex[:, i]):7.2f} us (last search)")
+it1 = (raw.reshape(-1)[3584:3584 + 8 * 64].astype(np.int64).reshape(64, 8) - t[:, 0].min()) / 100.0
+for i, n in enumerate(["iteration 1 starts", "its MFMA phase done", "barrier passed", "partials summed", "bounds sorted", "publishes + staging done"]):
+    print(f"{n:30s}: median {np.median(it1[:, i]):7.2f} us (workgroups 0..63, last search)")
+fl = raw.reshape(-1)[2048:2048 + G].astype(np.int64)
+print("mid-scan flushes per workgroup (last search): count histogram", np.bincount((fl & 0xffff).astype(int))[:6],
+      "| staged at the last flush (median)", int(np.median((fl >> 16) & 0xffffff)), "| tile of the last flush (median)", int(np.median(fl >> 40)))
 tiles = (rows + 31) // 32
 print(f"tiles per workgroup: {tiles / G:.2f}; per-tile time in the loop (median wg): "
       f"{np.median((a[:, 2] - a[:, 1])) / max(tiles / G - 1, 1):.2f} us")
