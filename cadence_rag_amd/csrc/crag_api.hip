@@ -108,7 +108,6 @@ struct crag_index {
     // rows in fp32's comfortable range, so such an index always takes the plain fp32 scan
     bool irregular = false;
     uint32_t *irregular_dev = nullptr;
-    unsigned long long *pf_stamps = nullptr; // developer probe (CRAG_PF_STAMPS=1): 4 stamps per scan workgroup
     unsigned long long *pf_stats = nullptr;  // device: candidates, rescored rows, searches (prefilter path)
     const char *last_scan_kernel = "";  // name of the scan kernel the most recent search launched
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
@@ -295,7 +294,6 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.reverse = sp.reverse;
         fp.sets = k <= 24 ? 1 : (k <= 48 ? 2 : 4);
         fp.cap = cap;
-        fp.stamps = ix->pf_stamps;
         const int nqb = wide ? 2 : 1;
         HIP_TRY(crag::launch_prefilter(fp, nqb, nq_pad / (32 * nqb), st, &ix->last_scan_kernel));
         if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
@@ -414,8 +412,6 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_reverse = getenv("CRAG_NO_REVERSE") != nullptr;
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
-    if (getenv("CRAG_PF_STAMPS") && hipMalloc((void **)&ix->pf_stamps, 4 * 1024 * sizeof(unsigned long long)) != hipSuccess)
-        ix->pf_stamps = nullptr;
     if ((e = hipMalloc((void **)&ix->irregular_dev, sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&ix->pf_stats, 4 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ix->irregular_dev, 0, sizeof(uint32_t))) != hipSuccess ||
@@ -440,7 +436,6 @@ int crag_index_destroy(crag_index *ix) {
     }
     if (ix->irregular_dev) (void)hipFree(ix->irregular_dev);
     if (ix->pf_stats) (void)hipFree(ix->pf_stats);
-    if (ix->pf_stamps) (void)hipFree(ix->pf_stamps);
     if (ix->corpus) (void)hipFree(ix->corpus);
     if (ix->inv_norm) (void)hipFree(ix->inv_norm);
     if (ix->ids) (void)hipFree(ix->ids);
@@ -795,15 +790,6 @@ int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candi
     if (candidates) *candidates = (int64_t)v[0];
     if (rescored_rows) *rescored_rows = (int64_t)v[1];
     if (searches) *searches = (int64_t)v[2];
-    return CRAG_OK;
-}
-
-/* developer probe, not part of include/crag_dense.h: the last prefilter scan's per-workgroup stamps */
-int crag_debug_pf_stamps(crag_index *ix, unsigned long long *out, int n_groups) {
-    if (!ix || !ix->pf_stamps) return fail(CRAG_EINVAL, "stamps not enabled (CRAG_PF_STAMPS=1)");
-    DeviceGuard guard(ix->device);
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, ix->pf_stamps, (size_t)n_groups * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRAG_OK;
 }
 

@@ -82,7 +82,6 @@ struct PfParams {
     int64_t n_rows;
     int nq, k, G, reverse;
     int sets;                 // 1, 2 or 4 class sets (<= k)
-    unsigned long long *stamps;  // nullable (developer probe): per workgroup 4 s_memrealtime stamps (100 MHz)
     int cap;
 };
 

@@ -1691,9 +1691,6 @@ template <int NQB>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB, SETS = 1;
     __shared__ PfLds<NQB> L;
-    const unsigned long long stamp0 = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) p.stamps[2048 + blockIdx.x] = 0ull;
-    unsigned long long stamp1 = 0ull, stamp2 = 0ull;
     ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
     {   // whole tiles per workgroup (see prefilter_refresh_kernel)
         const int64_t nt = (p.n_rows + 31) >> 5;
@@ -1710,7 +1707,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         const int R = w * RPO, qb = R >> 4, r = R & 15;
         o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
-        o.okmask = 0u;  // filled in below, once the corpus and query loads are on their way
+        o.okmask = 0u;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            if (o.qg0 + e < p.nq && p.qinv[o.qg0 + e] > 0.f) o.okmask |= 1u << e;
     }
     if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.n_stage = 0u;
@@ -1734,23 +1734,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
     }
-    float own_qinv[RPO];  // 1/||q|| of the owned queries (the prepared array covers the padded queries: 0 there);
-#pragma unroll            // loaded behind the corpus and query fragments: 4 dependent round trips in front of them
-    for (int e = 0; e < RPO; ++e) own_qinv[e] = p.qinv[o.qg0 + e];  // cost 3.7 us of every launch
     float stash[RPO];  // the first tile's scores (NaN = not eligible): judged at the end, when bounds exist
 #pragma unroll
     for (int e = 0; e < RPO; ++e) stash[e] = __uint_as_float(0x7fc00000u);
     uint32_t stash_row = 0u;
     float inv_cur = 0.f;
     if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
-    if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) p.stamps[2560 + c.g * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
-#pragma unroll
-    for (int e = 0; e < RPO; ++e)
-        if (o.qg0 + e < p.nq && own_qinv[e] > 0.f) o.okmask |= 1u << e;
-    if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) p.stamps[2560 + c.g * 4 + 1] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
-    if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) p.stamps[2560 + c.g * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // k_s of set s: the (k_s)-th largest class maximum of the set is reached by k_s distinct rows (SETS <= k)
     const int k_base = p.k / SETS, k_rem = p.k % SETS;
@@ -1784,9 +1775,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     };
 
     int buf = 0;
-#define PF_STAMP(SLOT_) if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0 && c.g < 64 && ti == 1) p.stamps[3584 + c.g * 8 + (SLOT_)] = __builtin_amdgcn_s_memrealtime()
     for (int ti = 0; ti < c.n_tiles; ++ti) {
-        PF_STAMP(0);
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
@@ -1819,8 +1808,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0 && ti == 0) p.stamps[2560 + c.g * 4 + 3] = __builtin_amdgcn_s_memrealtime();
-        PF_STAMP(1);
         // split-K: owner wave ow gets registers [ow*RPO, ow*RPO+RPO) of every producer
 #pragma unroll
         for (int ow = 0; ow < SCAN_WAVES; ++ow) {
@@ -1830,14 +1817,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             L.slab[buf][ow][w][lane] = v;
         }
         // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) {
-            if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) p.stamps[2048 + c.g] += 1ull + ((unsigned long long)L.n_stage << 16) + ((unsigned long long)ti << 40);
-            pf_flush<NQB>(p, L, c.t_begin * 32);
-        }
-        if (p.stamps && ti == 0) stamp1 = __builtin_amdgcn_s_memrealtime();
-        PF_STAMP(2);
-        if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0 && (c.g & 31) == 0 && ti < 16)
-            p.stamps[1024 + (c.g >> 5) * 16 + ti] = __builtin_amdgcn_s_memrealtime();  // per-tile timeline of 8 workgroups
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
         float sc[RPO], thr[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
@@ -1848,9 +1828,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) sc[e] += v[e];
         }
         buf ^= 1;
-        PF_STAMP(3);
         thresholds(gb, thr);
-        PF_STAMP(4);
         const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
         const int set = (int)(tile & (int64_t)(SETS - 1));
         bool pass[RPO];
@@ -1864,10 +1842,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int s = 1; s < SETS; ++s) seen = (s == set) ? gb[e][s] : seen;
             const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
             // On the first tile every class is empty and every lane would publish: 524 000 atomics on 2048 cells
-            // from all workgroups at once, and the next tile's bound loads queue up behind them (measured: the
-            // second tile took 17 us instead of 6).  There only the tile's best row per query publishes: the k
-            // best of the 8192 first-tile rows are their tiles' best with high probability, so the bound after
-            // the first tile is as good, from 16 000 atomics.
+            // from all workgroups at once, and the next tile's bound loads queue up behind them (measured with
+            // in-kernel stamps: the second tile took 17 us instead of 12.6).  There only the tile's best row per
+            // query publishes: the k best of the 8192 first-tile rows are their tiles' best with high
+            // probability, so the bound after the first tile is as good, from 16 000 atomics.
             bool lift = ord > seen;
             if (ti == 0) lift = lift && (ord == half_max_u32(ord));
             if (lift)
@@ -1882,11 +1860,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         } else {
             pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
         }
-        PF_STAMP(5);
         inv_cur = inv_nxt;
     }
-#undef PF_STAMP
-    if (p.stamps) stamp2 = __builtin_amdgcn_s_memrealtime();
     if (c.n_tiles > 0) {  // the first tile against the final bounds
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
         uint32_t gb[RPO][SETS];
@@ -1899,13 +1874,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
     }
     pf_flush<NQB>(p, L, c.t_begin * 32);
-    if (p.stamps && threadIdx.x == 0 && blockIdx.y == 0) {
-        unsigned long long *o4 = p.stamps + 4 * (size_t)c.g;
-        o4[0] = stamp0;
-        o4[1] = stamp1;
-        o4[2] = stamp2;
-        o4[3] = __builtin_amdgcn_s_memrealtime();
-    }
 }
 
 // ---- K1, k > 24 (two or four class sets): bounds derived on refresh tiles only and shared through a word per query --
@@ -1931,7 +1899,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
         const int R = w * RPO, qb = R >> 4, r = R & 15;
         o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
-        o.okmask = 0u;  // filled in below, once the corpus and query loads are on their way
+        o.okmask = 0u;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            if (o.qg0 + e < p.nq && p.qinv[o.qg0 + e] > 0.f) o.okmask |= 1u << e;
     }
     if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.n_stage = 0u;
@@ -1955,9 +1926,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
     }
-    float own_qinv[RPO];  // 1/||q|| of the owned queries (the prepared array covers the padded queries: 0 there);
-#pragma unroll            // loaded behind the corpus and query fragments: 4 dependent round trips in front of them
-    for (int e = 0; e < RPO; ++e) own_qinv[e] = p.qinv[o.qg0 + e];  // cost 3.7 us of every launch
     // Candidate decisions lag the scores: tile t is judged at the end of iteration t+1, with the bound known then
     // (every workgroup's publishes of tile t-1 and most of tile t have landed), and the first tile, scored before
     // any bound exists, waits in LDS and is judged last of all.  NaN = not eligible.
@@ -1972,9 +1940,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
     float inv_cur = 0.f;
     if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
-#pragma unroll
-    for (int e = 0; e < RPO; ++e)
-        if (o.qg0 + e < p.nq && own_qinv[e] > 0.f) o.okmask |= 1u << e;
     __syncthreads();
 
     const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
