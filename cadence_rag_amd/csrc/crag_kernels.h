@@ -50,11 +50,9 @@ struct MergeParams {
 };
 
 // ---- prefilter path (fp16 MFMA scan + exact rescoring), see crag_search.hip --------------------------------
-// per-query bound record: 128 class maxima (4 sets x 32 row classes), then the shared bound tau in a line of its
-// own -- every wave of every workgroup reads tau on every tile: 64 taus packed into two cache lines made those
-// two lines a hot spot that cost 10-20 us per tile
+// per-query bound record: 128 class maxima (4 sets x 32 row classes), padded to five 128-byte lines so that the
+// records of two queries never share a line
 constexpr int PF_BOUND_CELLS = 160;
-constexpr int PF_TAU_CELL = 128;
 constexpr int PF_MIN_ROWS_PER_GROUP = 128;    // below this many rows per workgroup the plain fp32 scan is used
 
 struct PrepParams {

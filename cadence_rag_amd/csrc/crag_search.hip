@@ -1554,11 +1554,29 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(PrepParams p) {
     }
 }
 
+// lane ^ X inside each 32-lane half on the VALU (DPP) where a pattern exists (ds_swizzle costs an LDS round trip per
+// stage: 20 us of a 690 us scan went into the 15 stages of the sort below).  scripts/probes/dpp_xor_check.hip
+// checks every pattern against ds_swizzle on the device.
+template <int X>
+__device__ __forceinline__ uint32_t dpp_xor(uint32_t v, int lane) {
+    if constexpr (X == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (X == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (X == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    else if constexpr (X == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (X == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true); // row_mirror
+    else if constexpr (X == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    else if constexpr (X == 4) {
+        const uint32_t up = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x12C, 0xF, 0xF, true);  // row_ror:12: lane i <- i+4
+        const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xF, 0xF, true);  // row_ror:4:  lane i <- i-4
+        return (lane & 4) ? dn : up;
+    } else return swz_xor<X>(v);
+}
+
 // sort the 32 values of each half-wave, descending with the lane index
 __device__ __forceinline__ uint32_t sort32_desc_u32(uint32_t v, int lane) {
 #define CRAG_CX(X_, BIT_)                                              \
     {                                                                  \
-        const uint32_t o_ = swz_xor<X_>(v);                            \
+        const uint32_t o_ = dpp_xor<X_>(v, lane);                      \
         const bool mx_ = !(lane & BIT_);                               \
         v = mx_ ? (o_ > v ? o_ : v) : (o_ < v ? o_ : v);               \
     }
@@ -1568,54 +1586,11 @@ __device__ __forceinline__ uint32_t sort32_desc_u32(uint32_t v, int lane) {
     return v;
 }
 
-// (rank+1)-th largest (rank = 0 .. 32*S-1) of the 32*S values a half-wave holds, S per lane: bitonic sort of the
-// elements i = s*32 + (lane & 31), descending; exchanges at distance >= 32 stay inside the lane.
-template <int S>
-__device__ __forceinline__ uint32_t kth_largest_cells(uint32_t (&v)[S], int rank, int lane) {
-    constexpr int N = 32 * S;
-    static_for<1, 8>([&](auto LS) {  // block size 2^LS
-        constexpr int size = 1 << decltype(LS)::value;
-        if constexpr (size <= N) {
-            static_for<0, decltype(LS)::value>([&](auto LT) {
-                constexpr int stride = size >> (1 + decltype(LT)::value);
-                if constexpr (stride >= 32) {
-                    constexpr int ds = stride >> 5;
-#pragma unroll
-                    for (int s0 = 0; s0 < S; ++s0) {
-                        if ((s0 & ds) == 0) {
-                            const bool desc = size >= N || ((s0 * 32) & size) == 0;  // uniform: size >= 64 here
-                            const uint32_t a = v[s0], b = v[s0 | ds];
-                            const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
-                            v[s0] = desc ? hi : lo;
-                            v[s0 | ds] = desc ? lo : hi;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int s0 = 0; s0 < S; ++s0) {
-                        const int i = s0 * 32 + (lane & 31);
-                        const bool desc = size >= N || (i & size) == 0;
-                        const bool keep_max = desc == ((lane & stride) == 0);
-                        const uint32_t o = swz_xor<stride>(v[s0]);
-                        v[s0] = keep_max ? (o > v[s0] ? o : v[s0]) : (o < v[s0] ? o : v[s0]);
-                    }
-                }
-            });
-        }
-    });
-    uint32_t r = v[0];
-#pragma unroll
-    for (int s0 = 1; s0 < S; ++s0) r = ((rank >> 5) == s0) ? v[s0] : r;
-    return (uint32_t)__shfl((int)r, (lane & 32) | (rank & 31));
-}
-
 template <int NQB>
 struct PfLds {
     typedef float slab_t __attribute__((ext_vector_type(2 * NQB)));
     slab_t slab[2][SCAN_WAVES][SCAN_WAVES][64];  // [buf][owner wave][producer wave][lane]: split-K partial sums
     uint2 stage[PF_STAGE];                       // staged candidates: x = orderable score, y = (row - window) << 6 | query
-    float stash[SCAN_WAVES][2 * NQB][64];       // the first tile's scores, judged when the scan is over
-    uint32_t tau[SCAN_WAVES][2][2 * NQB];       // each half-wave's view of the bounds of its queries (0 = none yet)
     uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
     uint32_t n_stage;
 };
@@ -1679,20 +1654,27 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
 }
 
 // ---- K1: the fp16 scan.  Grid (G, passes); one pass = 32*NQB queries against this workgroup's row range ------
-// ---- K1, k <= 24 (one class set): the fp16 scan.  Grid (G, passes); one pass = 32*NQB queries against this
-// workgroup's row range.  Every tile: the 32 class maxima of each owned query are loaded (issued in front of the
-// next tile's corpus loads, used after the MFMA phase), sorted across the half-wave, the k-th largest is the
-// bound; a row that beats its class maximum publishes it (atomic max).  Measured against the variant below that
-// derives bounds on every fourth tile only and shares them through a word per query (same box, 64 queries):
-// 100 us vs 126 us at 100 000 rows, 683 us vs 769 us at 1M -- the bookkeeping of the shared bound (its
-// device-coherent loads and atomics sit in the same in-order queue as the corpus stream) costs more than four
-// 15-stage sorts per tile.  For k > 24 (two or four class sets, 8-16 sorts per tile) the balance tips.
-template <int NQB>
+// A lane keeps the maxima of ITS rows (class = lane x tile parity: the rows of a class within a workgroup all belong
+// to one lane) in registers, and the workgroups exchange them on a geometric schedule only: publish after tiles 0,
+// 3, 15, 63, ... (atomic max of the class maxima that rose since the last checkpoint and beat the bound), read the
+// shared maxima + sort two tiles after each.  A bound derived from the first t tiles of every workgroup lets about
+// 12 n/t rows per query pass (k = 10, n tiles per workgroup) and holds for the next 3t tiles, so every interval adds
+// the same ~36 candidates per query: log4(n) exchanges per workgroup for a few dozen candidates per query.  All
+// other tiles touch no shared word.
+// [The first version exchanged on every tile: bound loads in front of the MFMA phase, a sort, an atomic max for
+// every row that beat its class.  Switching its parts off on one box (100 000 rows x 64 queries / 1M x 64): nothing
+// exchanged and no candidates 64.6 / 641 us; + bound loads of lines nobody writes 66.2 / 651; + the atomic maxima
+// 91.3 / 658; + sorts and candidate staging 104.5 / 690.  A device-scope atomic is carried out at the memory side
+// and acknowledged microseconds later; it sits in the same in-order queue as the corpus loads of its wave, a
+// stalled wave stalls its workgroup at the next barrier, and while bounds are young some wave of every workgroup
+// lifts a class maximum on nearly every tile.  Plain stores instead of atomics ran at 78 / 626 us but lose
+// maxima (20x the candidates); eight copies of the cells (one per XCD) weaken the bound 10x for no gain.]
+template <int NQB, int SETS>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
-    constexpr int RPO = 2 * NQB, SETS = 1;
+    constexpr int RPO = 2 * NQB;
     __shared__ PfLds<NQB> L;
     ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
-    {   // whole tiles per workgroup (see prefilter_refresh_kernel)
+    {   // whole tiles per workgroup
         const int64_t nt = (p.n_rows + 31) >> 5;
         c.t_begin = (nt * c.g) / p.G;
         const int64_t t_end = (nt * (c.g + 1)) / p.G;
@@ -1734,279 +1716,91 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
     }
-    float stash[RPO];  // the first tile's scores (NaN = not eligible): judged at the end, when bounds exist
+    // the first two tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
+    float stash[RPO], stash2[RPO];
 #pragma unroll
-    for (int e = 0; e < RPO; ++e) stash[e] = __uint_as_float(0x7fc00000u);
+    for (int e = 0; e < RPO; ++e) stash2[e] = __uint_as_float(0x7fc00000u);
+    uint32_t stash2_row = 0u;
+    float thr[RPO];    // candidate thresholds of the owned queries (bound - 2 delta)
+    uint32_t tau[RPO];            // the bound itself, orderable (0 = none yet)
+    uint32_t lmax[RPO][SETS];     // class maxima over this lane's own rows
+    uint32_t dirty = 0u;          // bit e*SETS+s: lmax[e][s] has risen since the last publish
+#pragma unroll
+    for (int e = 0; e < RPO; ++e) {
+        stash[e] = __uint_as_float(0x7fc00000u);
+        thr[e] = -__builtin_inff();
+        tau[e] = 0u;
+#pragma unroll
+        for (int s = 0; s < SETS; ++s) lmax[e][s] = 0u;
+    }
     uint32_t stash_row = 0u;
     float inv_cur = 0.f;
     if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
     __syncthreads();
 
-    // k_s of set s: the (k_s)-th largest class maximum of the set is reached by k_s distinct rows (SETS <= k)
     const int k_base = p.k / SETS, k_rem = p.k % SETS;
     const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
+    // a record of zeros nobody writes, one per workgroup: where the loads of a padded / zero query go (no branch
+    // per query around the loads)
+    const uint32_t *const idle_row = p.gbound + ((size_t)gridDim.y * (32 * NQB) + c.g) * PF_BOUND_CELLS + j;
 
-    // class maxima of the owned queries, device-coherent loads (they are updated by every workgroup)
     auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
-        for (int e = 0; e < RPO; ++e)
+        for (int e = 0; e < RPO; ++e) {
+            const bool live = (o.okmask >> e) & 1u;
 #pragma unroll
             for (int s = 0; s < SETS; ++s)
-                gb[e][s] = ((o.okmask >> e) & 1u)
-                               ? __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                               : 0u;
+                gb[e][s] = __hip_atomic_load(live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row + s * 32,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
-    // candidate thresholds of the owned queries: min over the sets of the (k_s)-th largest class maximum, - 2 delta
-    auto thresholds = [&](const uint32_t (&gb)[RPO][SETS], float (&thr)[RPO]) {
+    // bound of a query: min over the sets of the (k_s)-th largest class maximum of the set (sum k_s = k)
+    auto derive = [&](const uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
-            uint32_t tau = 0xffffffffu;
+            uint32_t t = 0xffffffffu;
 #pragma unroll
             for (int s = 0; s < SETS; ++s) {
                 const uint32_t sorted = sort32_desc_u32(gb[e][s], lane);
                 const int ks = k_base + (s < k_rem ? 1 : 0);
                 const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
-                tau = kth < tau ? kth : tau;
+                t = kth < t ? kth : t;
             }
-            thr[e] = tau == 0u ? -__builtin_inff() : ord2f(tau) - 2.f * PF_DELTA;
+            if (t > tau[e]) {  // (a stale read can only be lower)
+                tau[e] = t;
+                thr[e] = ord2f(t) - 2.f * PF_DELTA;
+            }
         }
     };
 
+    // publish after tiles 0, 3, 15, 63, ...; read two tiles later (2, 5, 17, 65, ...): the atomics of every
+    // workgroup have had a tile time to land and the lines are quiet again when they are read (reading on the very
+    // next tile, with one stashed tile: 82 us instead of 73 at 100 000 rows x 64)
+    int next_pub = 0, next_read = 2, read_base = 1;
     int buf = 0;
     for (int ti = 0; ti < c.n_tiles; ++ti) {
         const uint32_t vnext = tile_voff(c, ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
-        // operands of this tile's epilogue: issued behind the B loads of this tile (already in flight) and in
-        // front of the next tile's, so they have arrived when the MFMA phase ends
-        float inv_nxt = 0.f;
-        if (ti + 1 < c.n_tiles) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1)) * 32 + j];
+        const bool rd = ti == next_read;  // uniform
+        // operands of this tile's epilogue, behind the B loads of this tile (in flight) and in front of the next one's
+        const float inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1 < c.n_tiles ? ti + 1 : ti)) * 32 + j];
         uint32_t mword[RPO], gb[RPO][SETS];
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
             mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
                               : 0xffffffffu;
-        load_bounds(gb);
-
-        f32x16 acc[NQB];
-        static_for<0, 8>([&](auto T) {
-            constexpr int t8 = decltype(T)::value;
-            // two loads = dims {16 t8 + 4h + 0..3} and {16 t8 + 8 + 4h + 0..3} of row j: normalise, round to fp16
-            const f32x4 lo = __builtin_bit_cast(f32x4, b[2 * t8]) * inv_cur;
-            const f32x4 hi = __builtin_bit_cast(f32x4, b[2 * t8 + 1]) * inv_cur;
-            const f16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), f16x2);
-            const f16x2 p1 = __builtin_convertvector((f32x2{lo[2], lo[3]}), f16x2);
-            const f16x2 p2 = __builtin_convertvector((f32x2{hi[0], hi[1]}), f16x2);
-            const f16x2 p3 = __builtin_convertvector((f32x2{hi[2], hi[3]}), f16x2);
-            const f16x8 bf = f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
-#pragma unroll
-            for (int qb = 0; qb < NQB; ++qb)
-                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qb][t8], bf, t8 == 0 ? zero16 : acc[qb], 0, 0, 0);
-            b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8) * 1024, 0, 0);
-            b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // split-K: owner wave ow gets registers [ow*RPO, ow*RPO+RPO) of every producer
-#pragma unroll
-        for (int ow = 0; ow < SCAN_WAVES; ++ow) {
-            typename PfLds<NQB>::slab_t v;
-#pragma unroll
-            for (int e = 0; e < RPO; ++e) v[e] = acc[(ow * RPO + e) >> 4][(ow * RPO + e) & 15];
-            L.slab[buf][ow][w][lane] = v;
-        }
-        // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        float sc[RPO], thr[RPO];
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < SCAN_WAVES; ++ww) {
-            const typename PfLds<NQB>::slab_t v = L.slab[buf][w][ww][lane];
-#pragma unroll
-            for (int e = 0; e < RPO; ++e) sc[e] += v[e];
-        }
-        buf ^= 1;
-        thresholds(gb, thr);
-        const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
-        const int set = (int)(tile & (int64_t)(SETS - 1));
-        bool pass[RPO];
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) {
-            const bool ok = row_ok && ((o.okmask >> e) & 1u) && ((mword[e] >> j) & 1u) && (sc[e] == sc[e]);
-            sc[e] = ok ? sc[e] : __uint_as_float(0x7fc00000u);
-            // publish an improved class maximum (rare: only a row that beats everything seen in its class)
-            uint32_t seen = gb[e][0];
-#pragma unroll
-            for (int s = 1; s < SETS; ++s) seen = (s == set) ? gb[e][s] : seen;
-            const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
-            // On the first tile every class is empty and every lane would publish: 524 000 atomics on 2048 cells
-            // from all workgroups at once, and the next tile's bound loads queue up behind them (measured with
-            // in-kernel stamps: the second tile took 17 us instead of 12.6).  There only the tile's best row per
-            // query publishes: the k best of the 8192 first-tile rows are their tiles' best with high
-            // probability, so the bound after the first tile is as good, from 16 000 atomics.
-            bool lift = ord > seen;
-            if (ti == 0) lift = lift && (ord == half_max_u32(ord));
-            if (lift)
-                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-            pass[e] = sc[e] >= thr[e];
-        }
-        if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
-#pragma unroll
-            for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
-            stash_row = (uint32_t)(row - c.t_begin * 32);
-        } else {
-            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
-        }
-        inv_cur = inv_nxt;
-    }
-    if (c.n_tiles > 0) {  // the first tile against the final bounds
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        uint32_t gb[RPO][SETS];
-        float thr[RPO];
-        load_bounds(gb);
-        thresholds(gb, thr);
-        bool pass[RPO];
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
-        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
-    }
-    pf_flush<NQB>(p, L, c.t_begin * 32);
-}
-
-// ---- K1, k > 24 (two or four class sets): bounds derived on refresh tiles only and shared through a word per query --
-template <int NQB, int SETS>
-__global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParams p) {
-    constexpr int RPO = 2 * NQB;
-    __shared__ PfLds<NQB> L;
-    // row range of this workgroup: whole tiles (a partial tile costs a full trip through the loop here, where a
-    // trip is bound by memory latency, not by bytes), n_tiles_total split as evenly as whole tiles allow
-    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
-    {
-        const int64_t nt = (p.n_rows + 31) >> 5;
-        c.t_begin = (nt * c.g) / p.G;
-        const int64_t t_end = (nt * (c.g + 1)) / p.G;
-        c.n_tiles = (int)(t_end - c.t_begin);
-        c.r_begin = c.t_begin * 32;
-        c.r_end = t_end * 32 < p.n_rows ? t_end * 32 : p.n_rows;
-    }
-    const int lane = c.lane, w = c.w, j = c.j, h = c.h;
-
-    PfOwner<NQB> o;
-    {
-        const int R = w * RPO, qb = R >> 4, r = R & 15;
-        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
-        o.okmask = 0u;
-#pragma unroll
-        for (int e = 0; e < RPO; ++e)
-            if (o.qg0 + e < p.nq && p.qinv[o.qg0 + e] > 0.f) o.okmask |= 1u << e;
-    }
-    if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) L.n_stage = 0u;
-
-    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
-    u32x4 b[16];
-    {
-        const uint32_t v0 = tile_voff(c, 0);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
-    }
-    // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
-    // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
-    f16x8 a[NQB][8];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        const f16x8 *af = reinterpret_cast<const f16x8 *>(p.a16) +
-                          ((size_t)(((int)blockIdx.y * NQB + qb) * SCAN_WAVES + w) * 8) * 64 + lane;
-#pragma unroll
-        for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
-    }
-    // Candidate decisions lag the scores: tile t is judged at the end of iteration t+1, with the bound known then
-    // (every workgroup's publishes of tile t-1 and most of tile t have landed), and the first tile, scored before
-    // any bound exists, waits in LDS and is judged last of all.  NaN = not eligible.
-    float prev[RPO];
-    uint32_t *const tau = L.tau[w][h];  // this half-wave's view of the bounds (orderable scores), kept in LDS
-#pragma unroll
-    for (int e = 0; e < RPO; ++e) {
-        prev[e] = __uint_as_float(0x7fc00000u);
-        if (j == 0) tau[e] = 0u;
-        L.stash[w][e][lane] = __uint_as_float(0x7fc00000u);
-    }
-    float inv_cur = 0.f;
-    if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
-    __syncthreads();
-
-    const f32x16 zero16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
-    uint32_t *const tau_ptr = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + PF_TAU_CELL;  // + e * PF_BOUND_CELLS
-    // a record of zeros nobody writes, one per workgroup (behind the queries' records): where the bound loads of a
-    // non-refresh tile go
-    const uint32_t *const idle_row = p.gbound + ((size_t)gridDim.y * (32 * NQB) + c.g) * PF_BOUND_CELLS + j;
-
-    // Bounds.  The 32*SETS class maxima of a query (class = row position mod 32*SETS: lane x tile parity) belong to
-    // distinct rows, so their k-th largest is a lower bound on the k-th best approximate score; the shared cell tau
-    // of the query's record keeps the best such bound any wave has derived (atomic max).  A wave touches these
-    // device-coherent words only on its REFRESH tiles (the first three, then every REFRESH-th, staggered over the
-    // workgroups so that some workgroups refresh on every tile): it loads tau and the class maxima of its queries,
-    // selects the k-th largest with a half-wave bitonic sort and publishes an improvement.  In between it works
-    // with its own copy.  [Reading them on every tile made 256 workgroups hit the same 64 cache lines at once;
-    // the requests serialise per line (~25 ns each), loads return in order, and the corpus stream behind them
-    // waited: 6.9 us per tile instead of 5.3.]
-    // (Device-coherent loads bypass the caches: issued on every tile, even to a line nobody else touches, they
-    // are 16 000 scattered DRAM reads per tile time in the middle of the corpus stream.)
-    constexpr int REFRESH = 4 * SETS;
-    auto derive = [&](uint32_t (&gb)[RPO][SETS]) {
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) {
-            const uint32_t t = kth_largest_cells<SETS>(gb[e], p.k - 1, lane);
-            if (t > tau[e] && j == 0) {
-                tau[e] = t;
-                (void)__hip_atomic_fetch_max(tau_ptr + e * PF_BOUND_CELLS, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    auto threshold = [&](uint32_t t) { return t == 0u ? -__builtin_inff() : ord2f(t) - 2.f * PF_DELTA; };
-    auto row_in_window = [&](int ti) { return (uint32_t)(tile_of(c, ti) * 32 + j); };
-
-    // The bound words are loaded at the END of the iteration before a refresh tile and used in that tile's epilogue:
-    // they then sit behind the tile's corpus loads in the (in-order) return queue and can never hold corpus data
-    // back, whatever their latency; a whole MFMA phase later they have arrived.  Being the only loads under a
-    // branch, they make the compiler's count of outstanding loads conservative by their number, which only asks
-    // the MFMA phase of a refresh tile for corpus fragments it is about to need anyway.
-    auto is_refresh = [&](int ti) { return (ti < 4) || (((ti + c.g) & (REFRESH - 1)) == 0); };  // uniform over the workgroup
-    uint32_t gtau[RPO], gb[RPO][SETS], mword[RPO];
-#pragma unroll
-    for (int e = 0; e < RPO; ++e) {
-        gtau[e] = 0u;
-        mword[e] = 0xffffffffu;
-        if (p.mask && c.n_tiles > 0)
-            mword[e] = p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + c.t_begin + tile_of(c, 0)];
-#pragma unroll
-        for (int s = 0; s < SETS; ++s) gb[e][s] = 0u;
-    }
-    int buf = 0;
-#pragma clang loop unroll(disable)
-    for (int ti = 0; ti < c.n_tiles; ++ti) {
-        const bool refresh = ti > 0 && is_refresh(ti);  // the words loaded at the end of iteration ti-1 are live
-        const uint32_t vnext = tile_voff(c, ti + 1);
-        const int64_t tile = c.t_begin + tile_of(c, ti);
-        const int64_t row = tile * 32 + j;
+        if (rd) load_bounds(gb);
         // The whole tile before the first MFMA: the 16 loads of the next tile then leave back to back, 16 KiB
-        // contiguous per wave and 128 KiB per workgroup.  Consuming the fragments one by one as they arrive
-        // (exact waits) re-issues the loads in dribs and drabs interleaved with 2047 other waves, and the DRAM
-        // pages see it: measured 12 % slower.
+        // contiguous per wave.  Waiting fragment by fragment re-issues them in dribs and drabs between 2047 other
+        // waves' (measured on one box, 1M rows x 64: 643 us with this wait, 657 without).
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
             constexpr int t8 = decltype(T)::value;
-            // two loads = dims {16 t8 + 4h + 0..3} and {16 t8 + 8 + 4h + 0..3} of row j: normalise, round to fp16
             const f32x4 lo = __builtin_bit_cast(f32x4, b[2 * t8]) * inv_cur;
             const f32x4 hi = __builtin_bit_cast(f32x4, b[2 * t8 + 1]) * inv_cur;
             const f16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), f16x2);
@@ -2021,15 +1815,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
             b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
-        // split-K: owner wave ow gets registers [ow*RPO, ow*RPO+RPO) of every producer
 #pragma unroll
-        for (int ow = 0; ow < SCAN_WAVES; ++ow) {
+        for (int ow = 0; ow < SCAN_WAVES; ++ow) {  // split-K: owner wave ow gets registers [ow*RPO, ow*RPO+RPO)
             typename PfLds<NQB>::slab_t v;
 #pragma unroll
             for (int e = 0; e < RPO; ++e) v[e] = acc[(ow * RPO + e) >> 4][(ow * RPO + e) & 15];
             L.slab[buf][ow][w][lane] = v;
         }
-        // barrier + uniform decision: the wave whose append came last reads the final count, the OR spreads it
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
         float sc[RPO];
 #pragma unroll
@@ -2041,11 +1833,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
             for (int e = 0; e < RPO; ++e) sc[e] += v[e];
         }
         buf ^= 1;
-        if (refresh) {  // the idle record reads 0: nothing to merge on the other tiles
-#pragma unroll
-            for (int e = 0; e < RPO; ++e)
-                if (j == 0 && gtau[e] > tau[e]) tau[e] = gtau[e];
+        if (rd) {
             derive(gb);
+            // no bound yet for one of the queries (a workgroup far ahead of the others): ask again on the next tile
+            bool none = false;
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) none = none || (((o.okmask >> e) & 1u) && tau[e] == 0u);
+            if (__builtin_amdgcn_ballot_w64(none) != 0ull) {
+                next_read = ti + 1;
+            } else {
+                while (read_base * 4 + 1 <= ti) read_base *= 4;  // (terminates: read_base grows)
+                read_base *= 4;
+                next_read = read_base + 1;
+            }
         }
         const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
         const int set = (int)(tile & (int64_t)(SETS - 1));
@@ -2055,78 +1855,66 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_refresh_kernel(PfParam
             const bool ok = row_ok && ((o.okmask >> e) & 1u) && ((mword[e] >> j) & 1u) && (sc[e] == sc[e]);
             sc[e] = ok ? sc[e] : __uint_as_float(0x7fc00000u);
             const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
-            // Class maxima: only a row above the current bound can lift the k-th largest class maximum, so only
-            // such rows (the candidates, a few dozen per query and search) are published.  While no bound exists
-            // everything qualifies: then one workgroup in eight (another eighth on every tile) publishes a class,
-            // which fills every class 32 times over instead of 256 (an atomic storm on 32 cells per query otherwise).
-            const uint32_t te = tau[e];
-            const bool lift = te != 0u ? (ord > te) : (ord != 0u && (((c.g + j + ti) & 7) == 0));
-            if (lift)
-                (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + set * 32, ord, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT);
-            pass[e] = prev[e] >= threshold(te);  // the PREVIOUS tile against the bound known now
-        }
-        if (ti > 1) pf_stage<NQB>(L, o, prev, pass, row_in_window(ti - 1), p.flags);
-        if (ti == 0) {
 #pragma unroll
-            for (int e = 0; e < RPO; ++e) L.stash[w][e][lane] = sc[e];
+            for (int s = 0; s < SETS; ++s)
+                if (s == set && ord > lmax[e][s]) {
+                    lmax[e][s] = ord;
+                    dirty |= 1u << (e * SETS + s);
+                }
+            pass[e] = sc[e] >= thr[e];
+        }
+        if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
+            stash_row = (uint32_t)(row - c.t_begin * 32);
+        } else if (ti == 1) {
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) stash2[e] = sc[e];
+            stash2_row = (uint32_t)(row - c.t_begin * 32);
         } else {
-#pragma unroll
-            for (int e = 0; e < RPO; ++e) prev[e] = sc[e];
+            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
         }
-        {   // operands of the next iteration, behind its corpus loads (issued above) in the return queue
-            const int ti_nxt = ti + 1 < c.n_tiles ? ti + 1 : ti;  // the last iteration re-reads its own tile
-            const int64_t tile_nxt = c.t_begin + tile_of(c, ti_nxt);
-            inv_cur = p.inv_norm[tile_nxt * 32 + j];
-            if (p.mask) {
-#pragma unroll
-                for (int e = 0; e < RPO; ++e)
-                    mword[e] = p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile_nxt];
-            }
-        }
-        if (is_refresh(ti + 1)) {  // bound words for the next iteration, only if it is a refresh tile
+        if (ti == next_pub) {  // uniform
 #pragma unroll
             for (int e = 0; e < RPO; ++e) {
-                // a padded / zero query reads the idle record (zeros): no branch per query around the loads
-                const bool live = (o.okmask >> e) & 1u;
-                const uint32_t *tp = live ? tau_ptr + e * PF_BOUND_CELLS : idle_row;
-                gtau[e] = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int s = 0; s < SETS; ++s) {
-                    const uint32_t *gp = live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row;
-                    gb[e][s] = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t v = lmax[e][s];
+                    // only a class maximum above the bound can lift the bound.  After the first tile every class is
+                    // empty and every lane would publish (524 000 atomics on 2048 cells at once): there only the
+                    // tile's best row(s) per query do -- the k best of the first 8192 rows are their tiles' best
+                    // with high probability, so the first bound is as good, from 16 000 atomics (8 per class).
+                    bool lift = ((dirty >> (e * SETS + s)) & 1u) && v > tau[e];
+                    if (ti == 0) {
+                        if constexpr (SETS == 1) {
+                            lift = lift && (v == half_max_u32(v));
+                        } else {  // the tile's SETS best rows: a workgroup's first tile feeds one of the SETS sets
+                            const uint32_t sorted = sort32_desc_u32(v, lane);
+                            lift = lift && (v >= (uint32_t)__shfl((int)sorted, (lane & 32) | (SETS - 1)));
+                        }
+                    }
+                    if (lift)
+                        (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + s * 32, v, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            dirty = 0u;
+            next_pub = next_pub * 4 + 3;
         }
+        inv_cur = inv_nxt;
     }
-    if (c.n_tiles > 0) {  // the last tile and the first one against the final bounds
+    if (c.n_tiles > 0) {  // the first tile against the final bounds
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) {
-            const bool qok = (o.okmask >> e) & 1u;
-            const uint32_t gt = __hip_atomic_load(tau_ptr + e * PF_BOUND_CELLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (j == 0 && qok && gt > tau[e]) tau[e] = gt;
-#pragma unroll
-            for (int s = 0; s < SETS; ++s) {
-                const uint32_t v = __hip_atomic_load(gb_row + e * PF_BOUND_CELLS + s * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gb[e][s] = qok ? v : 0u;
-            }
-        }
+        uint32_t gb[RPO][SETS];
+        load_bounds(gb);
         derive(gb);
         bool pass[RPO];
-        if (c.n_tiles > 1) {
 #pragma unroll
-            for (int e = 0; e < RPO; ++e) pass[e] = prev[e] >= threshold(tau[e]);
-            pf_stage<NQB>(L, o, prev, pass, row_in_window(c.n_tiles - 1), p.flags);
-        }
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        float first[RPO];
+        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
+        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) {
-            first[e] = L.stash[w][e][lane];
-            pass[e] = first[e] >= threshold(tau[e]);
-        }
-        pf_stage<NQB>(L, o, first, pass, row_in_window(0), p.flags);
+        for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e];
+        pf_stage<NQB>(L, o, stash2, pass, stash2_row, p.flags);
     }
     pf_flush<NQB>(p, L, c.t_begin * 32);
 }
@@ -2439,13 +2227,13 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, p);     \
     } while (0)
     if (nqb == 2) {
-        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<2>);
-        else if (p.sets == 2) CRAG_LAUNCH(prefilter_refresh_kernel<2, 2>);
-        else CRAG_LAUNCH(prefilter_refresh_kernel<2, 4>);
+        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<2, 1>);
+        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<2, 2>);
+        else CRAG_LAUNCH(prefilter_kernel<2, 4>);
     } else {
-        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<1>);
-        else if (p.sets == 2) CRAG_LAUNCH(prefilter_refresh_kernel<1, 2>);
-        else CRAG_LAUNCH(prefilter_refresh_kernel<1, 4>);
+        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<1, 1>);
+        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<1, 2>);
+        else CRAG_LAUNCH(prefilter_kernel<1, 4>);
     }
 #undef CRAG_LAUNCH
     if (kernel_name) *kernel_name = name;

@@ -117,7 +117,9 @@ def test_candidate_overflow_falls_back_to_the_exact_scan(gpu, monkeypatch):
     n = 60_000
     corpus = unit_rows(rng, n)
     corpus[20_000:40_000] = corpus[7]
-    q = np.stack([corpus[7] * 2.0] + [rng.standard_normal(1024).astype(np.float32) for _ in range(39)])
+    others = rng.standard_normal((39, 1024)).astype(np.float32)
+    others -= np.outer(others @ corpus[7], corpus[7])   # orthogonal to the duplicated row: it never nears their top-k
+    q = np.concatenate([corpus[7][None] * 2.0, others])
     ix = _index(corpus, monkeypatch)
     try:
         ids, scores, counts = ix.search(q, 10)
