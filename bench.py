@@ -116,6 +116,7 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
     stats = index.prefilter_stats()
     return {"times": times, "n_launch": n_launch, "scan_us": scan_ms / max(n_launch, 1) * 1e3,
             "rest_us": rest_ms / max(n_launch, 1) * 1e3, "stats": stats, "kernel": index.last_scan_kernel(),
+            "row_bytes": (index.prefilter_row_bytes() if "prefilter" in index.last_scan_kernel() else DIM * 4),
             "out": (oi, osc, oc)}
 
 
@@ -146,8 +147,12 @@ def overlap_leg(index, queries, k, n_streams, steps):
 
 
 def roofline(rows, nq, k, leg, traffic_doc):
-    """algorithmic bytes = N*D*4 + Q*D*4 + Q*k*12 per launch, / the scan kernel's live event time."""
-    alg = rows * DIM * 4 + nq * DIM * 4 + nq * k * 12
+    """algorithmic bytes per launch = N * (row bytes the scan must stream) + Q*D*4 + Q*k*12, / the
+    scan kernel's live event time.  Row bytes: D*4 for a scan of the fp32 rows; D*2 when the index keeps the fp16
+    mirror of the unit rows and the prefilter scan streams that instead (8(d): a prefilter's bytes are declared
+    separately -- the fp32 rows are then read only for the rescored candidates, reported below)."""
+    row_bytes = leg.get("row_bytes") or DIM * 4
+    alg = rows * row_bytes + nq * DIM * 4 + nq * k * 12
     scan_s = leg["scan_us"] * 1e-6
     gbs = alg / scan_s / 1e9 if scan_s > 0 else 0.0
     q_pad = ((nq + 31) // 32) * 32
@@ -158,13 +163,18 @@ def roofline(rows, nq, k, leg, traffic_doc):
         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
         "kernel": leg["kernel"], "kernel_avg_us": round(leg["scan_us"], 2),
         "other_kernels_avg_us": round(leg["rest_us"], 2), "launches_timed": leg["n_launch"],
-        "algorithmic_bytes_per_launch": alg,
+        "algorithmic_bytes_per_launch": alg, "row_bytes_streamed": row_bytes,
         "matrix_pipe": ("fp16 MFMA (v_mfma_f32_32x32x16_f16), %.1f TFLOP/s of the 2500 dense peak: not the bound"
                         % (2.0 * q_pad * rows * DIM / scan_s / 1e12)) if prefilter else
                        ("fp32 MFMA %.1f TFLOP/s = %.3f of %.1f" % (2.0 * q_pad * rows * DIM / scan_s / 1e12,
                                                                     2.0 * q_pad * rows * DIM / scan_s / 1e12 / FP32_MFMA_PEAK_TFS,
                                                                     FP32_MFMA_PEAK_TFS)),
     }
+    if row_bytes != DIM * 4:
+        out["fp32_rows_equivalent_GBs"] = round(rows * DIM * 4 / scan_s / 1e9, 1) if scan_s > 0 else 0.0
+        out["note"] = ("the scan streams the fp16 mirror (D*2 bytes per row, + 50 % HBM footprint); "
+                       "fp32_rows_equivalent_GBs = N*D*4 / kernel time is what a scan of the fp32 rows would have to "
+                       "sustain for the same time -- not a roofline quantity")
     if prefilter:  # declared separately: rows re-read for the exact fp32 score, 4 KiB each
         out["rescored_rows_per_launch"] = round(leg["stats"]["rescored_rows"] / per, 1)
         out["rescored_bytes_per_launch"] = int(leg["stats"]["rescored_rows"] / per * DIM * 4)

@@ -86,6 +86,7 @@ struct crag_index {
     int64_t size = 0;
     int n_cu = 0;
     float *corpus = nullptr;
+    _Float16 *corpus16 = nullptr;  // fp16 mirror of the unit rows for the prefilter scan (CRAG_NO_FP16_MIRROR=1: none)
     float *inv_norm = nullptr;
     int64_t *ids = nullptr;
     // search workspaces are per stream (up to MAX_WS streams): searches enqueued on different streams
@@ -278,6 +279,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         // overflowed;  K3: exact rescoring + selection (or the merge of K2's lists)
         crag::PfParams fp;
         fp.corpus = ix->corpus;
+        fp.corpus16 = ix->corpus16;
         fp.inv_norm = ix->inv_norm;
         fp.a16 = (const _Float16 *)ws->a16.p;
         fp.qinv = (const float *)ws->qinv.p;
@@ -412,6 +414,18 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_reverse = getenv("CRAG_NO_REVERSE") != nullptr;
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
+    if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
+        // + 2 KiB per row beside the 4 KiB fp32 row: the prefilter scan then streams half the bytes.  Padding rows
+        // read as zeros (their positions are beyond every workgroup's row range anyway).
+        const size_t mbytes = (size_t)ix->cap_rows * crag::DIM * sizeof(_Float16);
+        if ((e = hipMalloc((void **)&ix->corpus16, mbytes)) != hipSuccess ||
+            (e = hipMemset(ix->corpus16, 0, mbytes)) != hipSuccess) {
+            int rc = fail(CRAG_ENOMEM, "hipMalloc for the fp16 mirror of %lld rows failed: %s", (long long)ix->cap_rows,
+                          hipGetErrorString(e));
+            crag_index_destroy(ix);
+            return rc;
+        }
+    }
     if ((e = hipMalloc((void **)&ix->irregular_dev, sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&ix->pf_stats, 4 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ix->irregular_dev, 0, sizeof(uint32_t))) != hipSuccess ||
@@ -437,6 +451,7 @@ int crag_index_destroy(crag_index *ix) {
     if (ix->irregular_dev) (void)hipFree(ix->irregular_dev);
     if (ix->pf_stats) (void)hipFree(ix->pf_stats);
     if (ix->corpus) (void)hipFree(ix->corpus);
+    if (ix->corpus16) (void)hipFree(ix->corpus16);
     if (ix->inv_norm) (void)hipFree(ix->inv_norm);
     if (ix->ids) (void)hipFree(ix->ids);
     for (auto &w : ix->ws) {
@@ -478,7 +493,7 @@ static int store_rows_locked(crag_index *ix, int64_t pos, const float *rows, int
             HIP_TRY(hipMemcpy(ix->stage_rows.p, src, (size_t)m * ix->dim * sizeof(float), hipMemcpyHostToDevice));
             src = (const float *)ix->stage_rows.p;
         }
-        HIP_TRY(crag::launch_store_rows(src, ix->dim, pos + o, m, ix->corpus, ix->inv_norm, ix->irregular_dev, 0));
+        HIP_TRY(crag::launch_store_rows(src, ix->dim, pos + o, m, ix->corpus, ix->inv_norm, ix->irregular_dev, ix->corpus16, 0));
         if (!dev) HIP_TRY(hipStreamSynchronize(0));  // staging buffer is reused by the next chunk
     }
     HIP_TRY(hipStreamSynchronize(0));
@@ -794,6 +809,11 @@ int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candi
 }
 
 const char *crag_index_last_scan_kernel(const crag_index *ix) { return ix ? ix->last_scan_kernel : ""; }
+
+int64_t crag_index_prefilter_row_bytes(const crag_index *ix) {
+    if (!ix || ix->env_no_prefilter) return 0;
+    return (int64_t)crag::DIM * (ix->corpus16 ? 2 : 4);
+}
 
 int crag_index_scan_geometry(const crag_index *ix, int nq, int *workgroups, int *threads,
                              int *query_blocks, int64_t *algorithmic_bytes_per_launch) {

@@ -68,12 +68,13 @@ struct PrepParams {
 
 struct PfParams {
     const float *corpus;
+    const _Float16 *corpus16; // fp16 mirror of the unit rows in B-operand order (nullable: scan the fp32 rows)
     const float *inv_norm;
     const _Float16 *a16;
     const float *qinv;
     const uint32_t *mask;
     int64_t mask_stride_w;
-    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS] class maxima + tau (orderable scores, atomic max)
+    uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS] class maxima (orderable scores, atomic max)
     uint2 *cand;              // [nq_pad][cap]: x = orderable approximate score, y = row position
     uint32_t *count;          // [nq_pad]
     uint32_t *flags;
@@ -122,7 +123,7 @@ hipError_t launch_finalize(const FinParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st);
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
-                             float *inv_norm, uint32_t *irregular, hipStream_t st);
+                             float *inv_norm, uint32_t *irregular, _Float16 *mirror, hipStream_t st);
 hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
                             hipStream_t st);
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,

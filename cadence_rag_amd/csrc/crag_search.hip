@@ -1419,9 +1419,15 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 
 // rows [n, dim] row-major -> tile32 layout at row positions [pos, pos+n); also 1/||row||.
 // One 256-thread block per row: thread kq moves dims [4kq, 4kq+3].
+// With a mirror (nullable): the unit row rounded to fp16, in the order the prefilter scan's MFMA wants its B
+// operand -- [tile][K slice w][k-step t8][lane (h, j)][8 halves], the halves being dims 128w + 16 t8 + 8 (e >> 2) +
+// 4h + (e & 3) -- computed exactly as the scan would on the fly (fp32 multiply by 1/||row||, v_cvt_pk_f16_f32), so a
+// scan of the mirror sees bit for bit the operand a scan of the fp32 rows builds in registers.
 __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int dim, int64_t pos,
-                                                         float *corpus, float *inv_norm, uint32_t *irregular) {
+                                                         float *corpus, float *inv_norm, uint32_t *irregular,
+                                                         _Float16 *mirror) {
     __shared__ double sh[4];
+    __shared__ float sh_inv;
     const int64_t i = blockIdx.x;
     const int kq = threadIdx.x;
     const float *src = rows + (size_t)i * dim;
@@ -1444,8 +1450,27 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int 
         float inv = ok ? (float)(1.0 / sqrt(ss)) : 0.f;
         if (!(inv > 0.f) || !(inv < 3.0e38f)) inv = 0.f;
         inv_norm[row] = inv;
+        sh_inv = inv;
         // a norm far outside fp32's comfortable range: the index is kept off the fp16 prefilter path
         if (inv > 0.f && (inv < 1.0e-30f || inv > 1.0e30f)) *irregular = 1u;
+    }
+    if (mirror) {
+        __syncthreads();
+        const float inv = sh_inv;
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x4 u = v * inv;
+        const f16x2_t lo = __builtin_convertvector((f32x2_t{u[0], u[1]}), f16x2_t);
+        const f16x2_t hi = __builtin_convertvector((f32x2_t{u[2], u[3]}), f16x2_t);
+        f16x4_t o = f16x4_t{lo[0], lo[1], hi[0], hi[1]};
+        if (!(inv > 0.f)) {  // never eligible: NaN scores, whatever the query
+            const _Float16 qnan = __builtin_bit_cast(_Float16, (unsigned short)0x7e00);
+            o = f16x4_t{qnan, qnan, qnan, qnan};
+        }
+        const int w = kq >> 5, d = (4 * kq) & 127, t8 = d >> 4, g = (d >> 3) & 1, h = (d >> 2) & 1;
+        const size_t idx = ((((size_t)(row >> 5) * SCAN_WAVES + w) * 8 + t8) * 64 + h * 32 + (size_t)(row & 31)) * 8 + 4 * g;
+        *reinterpret_cast<f16x4_t *>(mirror + idx) = o;
     }
 }
 
@@ -1669,7 +1694,7 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
 // stalled wave stalls its workgroup at the next barrier, and while bounds are young some wave of every workgroup
 // lifts a class maximum on nearly every tile.  Plain stores instead of atomics ran at 78 / 626 us but lose
 // maxima (20x the candidates); eight copies of the cells (one per XCD) weaken the bound 10x for no gain.]
-template <int NQB, int SETS>
+template <int NQB, int SETS, bool MIRROR>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB;
     __shared__ PfLds<NQB> L;
@@ -1697,14 +1722,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.n_stage = 0u;
 
-    const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
+    // B operand source.  fp32 rows (tile32 layout): two 16-byte loads per k-step, normalised and rounded to fp16
+    // in registers.  fp16 mirror (store_rows_kernel): one 16-byte load per k-step, already the MFMA operand --
+    // half the bytes per row; 64 KiB per tile, this wave's K slice = 8 KiB, a k-step = 1 KiB across the wave.
+    constexpr int NB = MIRROR ? 8 : 16;                       // loads per lane and tile
+    constexpr uint32_t TILE_BYTES = MIRROR ? TILE_FLOATS * 2 : TILE_FLOATS * 4;
+    const char *wg_base = MIRROR ? reinterpret_cast<const char *>(p.corpus16) + (size_t)c.t_begin * TILE_BYTES
+                                 : reinterpret_cast<const char *>(p.corpus) + (size_t)c.t_begin * TILE_BYTES;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(wg_base), 0, (int)((uint32_t)c.n_tiles * (uint32_t)(TILE_FLOATS * 4)), 0x00020000);
-    u32x4 b[16];
+        const_cast<char *>(wg_base), 0, (int)((uint32_t)c.n_tiles * TILE_BYTES), 0x00020000);
+    const uint32_t lane_off = MIRROR ? (uint32_t)(w * (8 * 1024) + lane * 16) : c.lane_off;
+    // byte offset of this lane's first load of the tile of step `step`, or the out-of-range marker (reads zeros)
+    auto voff = [&](int step) -> uint32_t {
+        const int t = tile_of(c, step);
+        const int64_t r = (c.t_begin + t) * 32 + j;
+        const bool valid = (step < c.n_tiles) && (r >= c.r_begin) && (r < c.r_end);
+        return valid ? (uint32_t)t * TILE_BYTES + lane_off : 0x80000000u;
+    };
+    u32x4 b[NB];
     {
-        const uint32_t v0 = tile_voff(c, 0);
+        const uint32_t v0 = voff(0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
     }
     // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
     // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
@@ -1734,8 +1773,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         for (int s = 0; s < SETS; ++s) lmax[e][s] = 0u;
     }
     uint32_t stash_row = 0u;
-    float inv_cur = 0.f;
-    if (c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
+    float inv_cur = 1.f;  // (mirror: rows that may never match are NaN in the mirror itself)
+    if (!MIRROR && c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
     __syncthreads();
 
@@ -1781,12 +1820,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     int next_pub = 0, next_read = 2, read_base = 1;
     int buf = 0;
     for (int ti = 0; ti < c.n_tiles; ++ti) {
-        const uint32_t vnext = tile_voff(c, ti + 1);
+        const uint32_t vnext = voff(ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
         const bool rd = ti == next_read;  // uniform
         // operands of this tile's epilogue, behind the B loads of this tile (in flight) and in front of the next one's
-        const float inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1 < c.n_tiles ? ti + 1 : ti)) * 32 + j];
+        float inv_nxt = 1.f;
+        if constexpr (!MIRROR) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1 < c.n_tiles ? ti + 1 : ti)) * 32 + j];
         uint32_t mword[RPO], gb[RPO][SETS];
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
@@ -1801,18 +1841,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         f32x16 acc[NQB];
         static_for<0, 8>([&](auto T) {
             constexpr int t8 = decltype(T)::value;
-            const f32x4 lo = __builtin_bit_cast(f32x4, b[2 * t8]) * inv_cur;
-            const f32x4 hi = __builtin_bit_cast(f32x4, b[2 * t8 + 1]) * inv_cur;
-            const f16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), f16x2);
-            const f16x2 p1 = __builtin_convertvector((f32x2{lo[2], lo[3]}), f16x2);
-            const f16x2 p2 = __builtin_convertvector((f32x2{hi[0], hi[1]}), f16x2);
-            const f16x2 p3 = __builtin_convertvector((f32x2{hi[2], hi[3]}), f16x2);
-            const f16x8 bf = f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+            f16x8 bf;
+            if constexpr (MIRROR) {
+                bf = __builtin_bit_cast(f16x8, b[t8]);
+            } else {  // two loads = dims {16 t8 + 4h + 0..3} and {16 t8 + 8 + 4h + 0..3} of row j
+                const f32x4 lo = __builtin_bit_cast(f32x4, b[2 * t8]) * inv_cur;
+                const f32x4 hi = __builtin_bit_cast(f32x4, b[2 * t8 + 1]) * inv_cur;
+                const f16x2 p0 = __builtin_convertvector((f32x2{lo[0], lo[1]}), f16x2);
+                const f16x2 p1 = __builtin_convertvector((f32x2{lo[2], lo[3]}), f16x2);
+                const f16x2 p2 = __builtin_convertvector((f32x2{hi[0], hi[1]}), f16x2);
+                const f16x2 p3 = __builtin_convertvector((f32x2{hi[2], hi[3]}), f16x2);
+                bf = f16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+            }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
                 acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qb][t8], bf, t8 == 0 ? zero16 : acc[qb], 0, 0, 0);
-            b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8) * 1024, 0, 0);
-            b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
+            if constexpr (MIRROR) {
+                b[t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + t8 * 1024, 0, 0);
+            } else {
+                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8) * 1024, 0, 0);
+                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
@@ -2226,15 +2275,22 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
         name = "crag::" #__VA_ARGS__;                                 \
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, p);     \
     } while (0)
+    const bool mirror = p.corpus16 != nullptr;
+#define CRAG_PICK(NQB_, SETS_)                                       \
+    do {                                                              \
+        if (mirror) CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, true>); \
+        else CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, false>);       \
+    } while (0)
     if (nqb == 2) {
-        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<2, 1>);
-        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<2, 2>);
-        else CRAG_LAUNCH(prefilter_kernel<2, 4>);
+        if (p.sets == 1) CRAG_PICK(2, 1);
+        else if (p.sets == 2) CRAG_PICK(2, 2);
+        else CRAG_PICK(2, 4);
     } else {
-        if (p.sets == 1) CRAG_LAUNCH(prefilter_kernel<1, 1>);
-        else if (p.sets == 2) CRAG_LAUNCH(prefilter_kernel<1, 2>);
-        else CRAG_LAUNCH(prefilter_kernel<1, 4>);
+        if (p.sets == 1) CRAG_PICK(1, 1);
+        else if (p.sets == 2) CRAG_PICK(1, 2);
+        else CRAG_PICK(1, 4);
     }
+#undef CRAG_PICK
 #undef CRAG_LAUNCH
     if (kernel_name) *kernel_name = name;
     return hipGetLastError();
@@ -2256,10 +2312,10 @@ hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st) {
 }
 
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
-                             float *inv_norm, uint32_t *irregular, hipStream_t st) {
+                             float *inv_norm, uint32_t *irregular, _Float16 *mirror, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, rows, dim, pos, corpus,
-                       inv_norm, irregular);
+                       inv_norm, irregular, mirror);
     return hipGetLastError();
 }
 

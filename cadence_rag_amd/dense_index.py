@@ -204,6 +204,10 @@ class DenseIndex:
                                                            ctypes.byref(c)), "prefilter_stats")
         return {"searches": a.value, "candidates": b.value, "rescored_rows": c.value}
 
+    def prefilter_row_bytes(self) -> int:
+        """Bytes of one corpus row the prefilter scan streams (2 KiB with the fp16 mirror, 4 KiB without, 0 = off)."""
+        return int(self._lib.crag_index_prefilter_row_bytes(self._h))
+
     def last_scan_kernel(self) -> str:
         """Name of the scan kernel the most recent search launched (as rocprofv3 prints it)."""
         name = self._lib.crag_index_last_scan_kernel(self._h)

@@ -169,6 +169,12 @@ int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candi
  * as rocprofv3 prints it; "" before the first search.  For bench.py's roofline object. */
 const char *crag_index_last_scan_kernel(const crag_index *ix);
 
+/* Bytes of one corpus row the prefilter scan streams: dim*2 when the index keeps the fp16 mirror of the unit rows
+ * (default; + dim*2 bytes of HBM per row beside the dim*4 fp32 row, which stays the source of truth: candidates
+ * are rescored from it), dim*4 when it was created with CRAG_NO_FP16_MIRROR=1, 0 with CRAG_NO_PREFILTER=1.
+ * the bytes of a prefilter are declared separately -- bench.py's roofline uses this figure. */
+int64_t crag_index_prefilter_row_bytes(const crag_index *ix);
+
 /* Launch geometry of the scan kernel for the current size (for DESIGN/bench reporting). */
 int crag_index_scan_geometry(const crag_index *ix, int nq, int *workgroups, int *threads,
                              int *query_blocks, int64_t *algorithmic_bytes_per_launch);

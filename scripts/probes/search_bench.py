@@ -37,7 +37,8 @@ def run(rows: int, nq: int, k: int, steps: int = 200) -> None:
     index.profile_enable(0)
     stats = index.prefilter_stats()
     per = max(stats["searches"], 1)
-    bytes_ = rows * 4096 + nq * 4096
+    row_bytes = index.prefilter_row_bytes() if "prefilter" in index.last_scan_kernel() else 4096
+    bytes_ = rows * row_bytes + nq * 4096
     scan_us = scan_ms / max(n, 1) * 1e3
     print(f"rows={rows} nq={nq} k={k}: step {dt * 1e6:8.1f} us  {nq / dt:10.0f} q/s | {index.last_scan_kernel()} "
           f"{scan_us:8.1f} us = {bytes_ / scan_us / 1e3:6.0f} GB/s ({bytes_ / scan_us / 1e3 / 8000:.3f} of 8 TB/s), "

@@ -22,6 +22,41 @@ def _index(corpus, monkeypatch, prefilter=True, ids=None):
     return ix
 
 
+def test_fp16_mirror_scan_equals_the_scan_of_the_fp32_rows(gpu, monkeypatch):
+    """The mirror holds exactly the operand the scan of the fp32 rows builds in registers (same multiply, same
+    rounding), so both prefilter scans feed the exact rescoring the same way: identical results, also after rows
+    were overwritten in place, and a row that may never match (zero norm) stays out through its NaN mirror."""
+    rng = np.random.default_rng(91)
+    n = 44_000
+    corpus = unit_rows(rng, n) * rng.uniform(0.1, 9.0, (n, 1)).astype(np.float32)
+    corpus[123] = 0.0
+    q = rng.standard_normal((64, 1024)).astype(np.float32)
+    fresh = unit_rows(rng, 500)
+    out = {}
+    for mirror in (True, False):
+        if mirror:
+            monkeypatch.delenv("CRAG_NO_FP16_MIRROR", raising=False)
+        else:
+            monkeypatch.setenv("CRAG_NO_FP16_MIRROR", "1")
+        ix = _index(corpus, monkeypatch)
+        try:
+            assert ix.prefilter_row_bytes() == (2048 if mirror else 4096)
+            first = ix.search(q, 10)
+            assert ("true" in ix.last_scan_kernel()) == mirror, ix.last_scan_kernel()
+            ix.update(20_000, fresh)
+            out[mirror] = (first, ix.search(q, 10), ix.search(q[:7], 100))
+        finally:
+            ix.close()
+    for a, b in zip(out[True], out[False]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+    assert 123 not in out[True][0][0]
+    after = corpus.copy()
+    after[20_000:20_500] = fresh
+    want = oracle.exact_topk(q[:3], after, 10, mode=oracle.F64, fast=True)
+    assert_topk_matches(out[True][1][0][:3], out[True][1][1][:3], out[True][1][2][:3], *want, tol=TOL)
+
+
 def _both(corpus, q, k, monkeypatch, mask=None):
     packed = None if mask is None else DenseIndex.pack_mask(mask)
     out = []
