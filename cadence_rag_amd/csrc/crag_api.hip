@@ -109,7 +109,7 @@ struct crag_index {
     // rows in fp32's comfortable range, so such an index always takes the plain fp32 scan
     bool irregular = false;
     uint32_t *irregular_dev = nullptr;
-    unsigned long long *pf_stats = nullptr;  // device: candidates, rescored rows, searches (prefilter path)
+    unsigned long long *pf_stats = nullptr;  // device: PF_STAT_SLOTS x {candidates, rescored rows, searches}
     const char *last_scan_kernel = "";  // name of the scan kernel the most recent search launched
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
@@ -427,9 +427,9 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
         }
     }
     if ((e = hipMalloc((void **)&ix->irregular_dev, sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&ix->pf_stats, 4 * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&ix->pf_stats, crag::PF_STAT_SLOTS * 3 * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ix->irregular_dev, 0, sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMemset(ix->pf_stats, 0, 4 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemset(ix->pf_stats, 0, crag::PF_STAT_SLOTS * 3 * sizeof(unsigned long long))) != hipSuccess) {
         int rc = fail(CRAG_ENOMEM, "hipMalloc for the index state failed: %s", hipGetErrorString(e));
         crag_index_destroy(ix);
         return rc;
@@ -798,10 +798,12 @@ int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candi
     if (!ix) return fail(CRAG_EINVAL, "index is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard guard(ix->device);
-    unsigned long long v[4] = {0, 0, 0, 0};
+    unsigned long long v[3] = {0, 0, 0};
+    std::vector<unsigned long long> rec((size_t)crag::PF_STAT_SLOTS * 3);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(v, ix->pf_stats, sizeof(v), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(ix->pf_stats, 0, sizeof(v)));
+    HIP_TRY(hipMemcpy(rec.data(), ix->pf_stats, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ix->pf_stats, 0, rec.size() * sizeof(unsigned long long)));
+    for (size_t i = 0; i < rec.size(); ++i) v[i % 3] += rec[i];
     if (candidates) *candidates = (int64_t)v[0];
     if (rescored_rows) *rescored_rows = (int64_t)v[1];
     if (searches) *searches = (int64_t)v[2];

@@ -53,6 +53,7 @@ struct MergeParams {
 // per-query bound record: 128 class maxima (4 sets x 32 row classes), padded to five 128-byte lines so that the
 // records of two queries never share a line
 constexpr int PF_BOUND_CELLS = 160;
+constexpr int PF_STAT_SLOTS = 1024;           // per-query statistics records (summed on the host when read)
 constexpr int PF_MIN_ROWS_PER_GROUP = 128;    // below this many rows per workgroup the plain fp32 scan is used
 
 struct PrepParams {
@@ -96,7 +97,7 @@ struct FinParams {
     int64_t *out_ids;
     float *out_scores;
     int32_t *out_counts;
-    unsigned long long *stats;  // nullable; [0] candidates, [1] rescored rows, [2] searches
+    unsigned long long *stats;  // nullable; PF_STAT_SLOTS records {candidates, rescored rows, searches}, record q % SLOTS
     int k, cap;
     MergeParams merge;          // used instead when flags[0] != 0 (the gated fp32 scan ran)
 };

@@ -2014,21 +2014,39 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     __shared__ int s_nbest, s_nsurv, s_rescored;
     __shared__ uint32_t s_kth;
     const int q = blockIdx.x, tid = threadIdx.x;
-    if (p.flags[0] != 0u) {  // uniform over the grid
+    // Everything the kernel needs first, in flight together (one memory round trip instead of a chain of four:
+    // flag -> count -> candidates -> ...): the overflow flag, the candidate count, the first MERGE_THREADS
+    // candidates (read before the count is known -- the list has `cap` >= MERGE_THREADS slots; the usual few dozen
+    // candidates are all among them), the query's norm and its fp32 fragments.
+    const uint2 *gcand = p.cand + (size_t)q * p.cap;
+    const uint32_t overflow = p.flags[0];
+    const uint32_t total = p.count[q];
+    const uint2 first = gcand[tid];
+    const float qinv = p.qinv[q];
+    // Statistics (bench.py's byte accounting): a record per query that only this workgroup updates -- read here,
+    // written back at the end with plain stores.  [They were three atomic adds on one shared record: 192 same-line
+    // device-scope atomics per search, whose acknowledgements the kernel's end had to wait for.]  Searches of more
+    // than PF_STAT_SLOTS queries, or on several streams at once, may lose counts; results never depend on them.
+    unsigned long long *const stat = p.stats ? p.stats + (size_t)(q % PF_STAT_SLOTS) * 3 : nullptr;
+    unsigned long long stat_old[3] = {0ull, 0ull, 0ull};
+    if (stat && tid == 0) {
+        stat_old[0] = stat[0];
+        stat_old[1] = stat[1];
+        stat_old[2] = stat[2];
+    }
+    // thread t = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
+    const f32x4 qfrag = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + (tid >> 5)) * 16 + ((tid >> 1) & 15)) * 64 + (tid & 1) * 32 + (q & 31)];
+    if (overflow != 0u) {  // uniform over the grid
         merge_partials_body(p.merge, q);
         return;
     }
     const int k = p.k;
-    const uint32_t total = p.count[q];
     const int C = (int)(total < (uint32_t)p.cap ? total : (uint32_t)p.cap);
-    const uint2 *gcand = p.cand + (size_t)q * p.cap;
     const bool in_lds = C <= FIN_ROUND;
+    if (tid < C) lcand[tid] = first;
     if (in_lds)
-        for (int e = tid; e < C; e += MERGE_THREADS) lcand[e] = gcand[e];
-    {   // thread t = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
-        const int w8 = tid >> 5, s16 = (tid >> 1) & 15, h2 = tid & 1;
-        qs[w8][s16][h2] = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + w8) * 16 + s16) * 64 + h2 * 32 + (q & 31)];
-    }
+        for (int e = tid + MERGE_THREADS; e < C; e += MERGE_THREADS) lcand[e] = gcand[e];
+    qs[tid >> 5][(tid >> 1) & 15][tid & 1] = qfrag;
     if (tid == 0) {
         s_nbest = 0;
         s_rescored = 0;
@@ -2122,7 +2140,6 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
 
     // 2. survivors -> exact scores, 8 lanes per row, in rounds of FIN_ROUND candidates
     const int grp = tid >> 3, sub = tid & 7;  // 32 rows per sweep; lane `sub` = K slice (the scan's wave w)
-    const float qinv = p.qinv[q];
     for (int r0 = 0; r0 < C; r0 += FIN_ROUND) {
         const int rn = (C - r0) < FIN_ROUND ? (C - r0) : FIN_ROUND;
         if (tid == 0) s_nsurv = 0;
@@ -2209,10 +2226,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     }
     if (tid == 0) {
         p.out_counts[q] = count;
-        if (p.stats) {  // candidates / rescored rows / searches, for bench.py's byte accounting
-            atomicAdd(&p.stats[0], (unsigned long long)total);
-            atomicAdd(&p.stats[1], (unsigned long long)s_rescored);
-            if (q == 0) atomicAdd(&p.stats[2], 1ull);
+        if (stat) {
+            stat[0] = stat_old[0] + (unsigned long long)total;
+            stat[1] = stat_old[1] + (unsigned long long)s_rescored;
+            if (q == 0) stat[2] = stat_old[2] + 1ull;
         }
     }
 }
