@@ -6,10 +6,15 @@
 // with hardware range checking, ds_swizzle cross-lane exchange.  See DESIGN.md for the layout
 // and the roofline arithmetic.
 //
-// HBM layout ("tile32"): the corpus is stored in tiles of 32 rows; inside a tile the float4
-// holding dims [4*kq, 4*kq+3] of row j lives at float4 index kq*32 + j.  One wave-instruction
-// `buffer_load_dwordx4` (64 lanes x 16 B) therefore reads 1 KiB of contiguous HBM AND lands
-// exactly in the B-operand lane map of v_mfma_f32_32x32x2_f32 (lane l: row l&31, k-half l>>5).
+// HBM layout ("tile32"): the corpus is stored in tiles of 32 rows; inside a tile a row is cut into 64 pieces of
+// 16 dims (64 bytes), and piece p of row j lives at byte (p*32 + j)*64.  The float4 holding dims [4*kq, 4*kq+3] of
+// row j is therefore at byte ((kq>>2)*32 + j)*64 + (kq&3)*16.  A wave-instruction `buffer_load_dwordx4` (lane l:
+// row l&31, float4 2s + (l>>5) of the wave's K slice) reads one half of 32 consecutive pieces -- every 128-byte
+// line it touches is completed by the next instruction -- and lands exactly in the B-operand lane map of
+// v_mfma_f32_32x32x2_f32 (lane l: row l&31, k-half l>>5).  The pieces are what the exact rescoring of single rows
+// (finalize_kernel) pays for: 64 lines per row.  [Float4-granular interleaving, piece = 16 bytes, made a scan
+// instruction read 1 KiB of contiguous HBM but a single row touch 256 lines: 78 us of a 166 us top-100 search
+// over 100 000 rows went into re-reading 8 400 rows.]
 // Queries are normalised once per call into the same layout (the A operand).
 //
 // scan kernel: one 512-thread workgroup per CU; the 8 waves split K = 1024 into 8 slices of
@@ -182,7 +187,7 @@ __device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int rever
     const int64_t t_end = (c.r_end > c.r_begin) ? ((c.r_end + 31) >> 5) : c.t_begin;
     c.n_tiles = (int)(t_end - c.t_begin);
     c.reverse = reverse != 0;
-    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.lane * 16);
+    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * 64 + c.h * 16);
     c.qloc[0] = c.qloc[1] = 0;
     c.qok[0] = c.qok[1] = false;
     c.mrow[0] = c.mrow[1] = nullptr;
@@ -210,6 +215,10 @@ __device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p) {
 // `step` counts tiles in processing order; a reversed pass walks the range back to front so that
 // the tail of the previous pass is still in the Infinity Cache (boustrophedon streaming)
 __device__ __forceinline__ int tile_of(const ScanCtx &c, int step) { return c.reverse ? c.n_tiles - 1 - step : step; }
+
+// byte offset, relative to tile_voff(), of a lane's s-th 16-byte load of a tile (s = 0..15 inside the wave's K
+// slice): float4 kq = 2s + h of the slice sits in the 64-byte piece kq >> 2 of its row, at (kq & 3) * 16
+__device__ __forceinline__ constexpr uint32_t b_soff(int s) { return (uint32_t)((s >> 1) * 2048 + (s & 1) * 32); }
 
 __device__ __forceinline__ uint32_t tile_voff(const ScanCtx &c, int step) {
     const int ti = tile_of(c, step);
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     {
         const uint32_t v0 = tile_voff(c, 0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff(s), 0, 0);
     }
     f32x4 a[16];
     load_queries(p, c, a, reinterpret_cast<double *>(&slab[0][0][0][0]));
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             acc = CRAG_MFMA(a[s][1], b[s][1], acc);
             acc = CRAG_MFMA(a[s][2], b[s][2], acc);
             acc = CRAG_MFMA(a[s][3], b[s][3], acc);
-            b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
+            b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(s), 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // split-K reduction through LDS (double-buffered: one barrier per tile)
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     {
         const uint32_t v0 = tile_voff(c, 0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff(s), 0, 0);
     }
     // A operand: the raw queries in fragment order (prep_queries_kernel), lane (i = lane&31, h = lane>>5) holds
     // q[i][128w + 8s + 4h + 0..3]: one coalesced 1 KiB load per s
@@ -679,7 +688,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
             constexpr int m = decltype(M)::value;
             constexpr int s = m >> 2, cc = m & 3;
             acc = CRAG_MFMA(a[s][cc], b[s][cc], acc);
-            if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
+            if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(s), 0, 0);
             if constexpr ((m & 1) == 0 && (m >> 1) < PIPE_OPS) {
                 pipe_bg<(m >> 1)>(p, c, slab, wbuf ^ 1, prev, st);
             }
@@ -966,7 +975,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
     u32x4 b[RING];
     uint32_t vcur = tile_voff(c, 0);
 #pragma unroll
-    for (int s = 0; s < RING; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + s * 1024, 0, 0);
+    for (int s = 0; s < RING; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + b_soff(s), 0, 0);
 
     // A operand: the raw queries of the block(s) in fragment order (prep_queries_kernel), lane (i = lane&31, h)
     // holds q[i][128w + 8s + 4h + 0..3]; 1/||q|| (also prepared) is applied to the score later
@@ -1059,15 +1068,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                     for (int ds = 0; ds < 2; ++ds) {
                         constexpr int base = 2 * grp;
                         const int st2 = base + ds;
-                        if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + (st2 + 8) * 1024, 0, 0);
-                        else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (st2 - 8) * 1024, 0, 0);
+                        if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + b_soff(st2 + 8), 0, 0);
+                        else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(st2 - 8), 0, 0);
                     }
                 }
             } else {
                 constexpr int s = m >> 2, cc = m & 3;
                 if constexpr (m == 0) acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], zero16);
                 else acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], acc[0]);
-                if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + s * 1024, 0, 0);
+                if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(s), 0, 0);
             }
             if constexpr ((m & 1) == 0 && m >= OPS0) {
                 constexpr int o = (m - OPS0) >> 1;
@@ -1440,7 +1449,7 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int 
             if (4 * kq + c < dim) v[c] = src[4 * kq + c];
     }
     const int64_t row = pos + i;
-    float *dst = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)kq * 32 + (row & 31)) * 4;
+    float *dst = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> 2) * 32 + (row & 31)) * 16 + (kq & 3) * 4;
     *reinterpret_cast<f32x4 *>(dst) = v;
     double ss = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
     ss = block_sum_256(ss, sh);
@@ -1479,7 +1488,7 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const float *corpus, int
     const int64_t i = blockIdx.x;
     const int kq = threadIdx.x;
     const int64_t row = pos + i;
-    const float *src = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)kq * 32 + (row & 31)) * 4;
+    const float *src = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> 2) * 32 + (row & 31)) * 16 + (kq & 3) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
     float *dst = rows + (size_t)i * dim;
 #pragma unroll
@@ -1743,7 +1752,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     {
         const uint32_t v0 = voff(0);
 #pragma unroll
-        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + s * 1024, 0, 0);
+        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (MIRROR ? (uint32_t)s * 1024u : b_soff(s)), 0, 0);
     }
     // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
     // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
@@ -1859,8 +1868,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             if constexpr (MIRROR) {
                 b[t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + t8 * 1024, 0, 0);
             } else {
-                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8) * 1024, 0, 0);
-                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + (2 * t8 + 1) * 1024, 0, 0);
+                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8), 0, 0);
+                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8 + 1), 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -1988,8 +1997,8 @@ __device__ __forceinline__ float exact_slice_dot(const f32x4 *qslice /* [16][2] 
     f32x4 c0[16], c1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        c0[s] = ctile[(2 * s) * 32 + jrow];
-        c1[s] = ctile[(2 * s + 1) * 32 + jrow];
+        c0[s] = ctile[((s >> 1) * 32 + jrow) * 4 + (2 * s & 3)];       // float4 kq = 2s of the slice: piece kq >> 2
+        c1[s] = ctile[((s >> 1) * 32 + jrow) * 4 + (2 * s & 3) + 1];
     }
     float acc = 0.f;
 #pragma unroll
