@@ -38,6 +38,10 @@ namespace crag {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// a row piece = 2^PIECE_SHIFT float4.  2 (64 bytes) measured against 3 and 4 on one box: 128-byte pieces make the
+// rescoring of a top-100 search 7 us cheaper (54 vs 61 us at 100 000 rows x 64 queries) but a scan instruction then
+// reads a quarter of each line it touches and the scan of the fp32 rows slows from 73 to 83 us.
+constexpr int PIECE_SHIFT = 2;
 
 // ------------------------------------------------------------------------------------------
 // key helpers: a candidate is the 64-bit key (orderable(score) << 32) | ~row ; larger = better
@@ -187,7 +191,7 @@ __device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int rever
     const int64_t t_end = (c.r_end > c.r_begin) ? ((c.r_end + 31) >> 5) : c.t_begin;
     c.n_tiles = (int)(t_end - c.t_begin);
     c.reverse = reverse != 0;
-    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * 64 + c.h * 16);
+    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * (16 << PIECE_SHIFT) + c.h * 16);
     c.qloc[0] = c.qloc[1] = 0;
     c.qok[0] = c.qok[1] = false;
     c.mrow[0] = c.mrow[1] = nullptr;
@@ -218,7 +222,9 @@ __device__ __forceinline__ int tile_of(const ScanCtx &c, int step) { return c.re
 
 // byte offset, relative to tile_voff(), of a lane's s-th 16-byte load of a tile (s = 0..15 inside the wave's K
 // slice): float4 kq = 2s + h of the slice sits in the 64-byte piece kq >> 2 of its row, at (kq & 3) * 16
-__device__ __forceinline__ constexpr uint32_t b_soff(int s) { return (uint32_t)((s >> 1) * 2048 + (s & 1) * 32); }
+__device__ __forceinline__ constexpr uint32_t b_soff(int s) {
+    return (uint32_t)(((2 * s) >> PIECE_SHIFT) * (512 << PIECE_SHIFT) + ((2 * s) & ((1 << PIECE_SHIFT) - 1)) * 16);
+}
 
 __device__ __forceinline__ uint32_t tile_voff(const ScanCtx &c, int step) {
     const int ti = tile_of(c, step);
@@ -1449,7 +1455,7 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int 
             if (4 * kq + c < dim) v[c] = src[4 * kq + c];
     }
     const int64_t row = pos + i;
-    float *dst = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> 2) * 32 + (row & 31)) * 16 + (kq & 3) * 4;
+    float *dst = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> PIECE_SHIFT) * 32 + (row & 31)) * (4 << PIECE_SHIFT) + (kq & ((1 << PIECE_SHIFT) - 1)) * 4;
     *reinterpret_cast<f32x4 *>(dst) = v;
     double ss = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
     ss = block_sum_256(ss, sh);
@@ -1488,7 +1494,7 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const float *corpus, int
     const int64_t i = blockIdx.x;
     const int kq = threadIdx.x;
     const int64_t row = pos + i;
-    const float *src = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> 2) * 32 + (row & 31)) * 16 + (kq & 3) * 4;
+    const float *src = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> PIECE_SHIFT) * 32 + (row & 31)) * (4 << PIECE_SHIFT) + (kq & ((1 << PIECE_SHIFT) - 1)) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
     float *dst = rows + (size_t)i * dim;
 #pragma unroll
@@ -1997,8 +2003,9 @@ __device__ __forceinline__ float exact_slice_dot(const f32x4 *qslice /* [16][2] 
     f32x4 c0[16], c1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        c0[s] = ctile[((s >> 1) * 32 + jrow) * 4 + (2 * s & 3)];       // float4 kq = 2s of the slice: piece kq >> 2
-        c1[s] = ctile[((s >> 1) * 32 + jrow) * 4 + (2 * s & 3) + 1];
+        // float4 kq = 2s (and 2s + 1) of the slice: piece kq >> PIECE_SHIFT of the row
+        c0[s] = ctile[(((2 * s) >> PIECE_SHIFT) * 32 + jrow) * (1 << PIECE_SHIFT) + ((2 * s) & ((1 << PIECE_SHIFT) - 1))];
+        c1[s] = ctile[(((2 * s) >> PIECE_SHIFT) * 32 + jrow) * (1 << PIECE_SHIFT) + ((2 * s) & ((1 << PIECE_SHIFT) - 1)) + 1];
     }
     float acc = 0.f;
 #pragma unroll
