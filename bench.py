@@ -541,8 +541,10 @@ def main() -> None:
                 "ms_per_step_median": round(statistics.median(times) / args.steps * 1e3, 5),
                 "ms_per_step_min": round(min(times) / args.steps * 1e3, 5),
                 "row_queries_per_s": round(rows_total * nq * args.steps / elapsed, 1),
-                "arithmetic": "fp16 MFMA prefilter with a proven error bound + exact fp32 rescoring of the "
-                              "survivors: results bit-identical to the fp32 scan (DESIGN.md 4)",
+                "arithmetic": "fp16 MFMA prefilter over the fp16 mirror of the unit rows (2 KiB per row beside the "
+                              "4 KiB fp32 row) with a proven error bound + exact fp32 rescoring of the survivors "
+                              "from the fp32 rows: results bit-identical to the fp32 scan (DESIGN.md 4)",
+                "hbm_bytes_per_corpus_row": DIM * 4 + (leg.get("row_bytes") if leg.get("row_bytes") != DIM * 4 else 0) + 12,
             },
             "roofline": roof,
         }

@@ -76,7 +76,8 @@ def traffic(fetch_csv: str, write_csv: str, workload: str, out_json: str) -> Non
         "FETCH_SIZE_KB": fetch_kb,
         "WRITE_SIZE_KB": write_kb,
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + (write_kb or 0.0) * 1024),
-        "algorithmic_bytes_per_launch": rows * 4096 + nq * 4096 + nq * k * 12,
+        # bytes of a row the scan streams: 2 KiB from the fp16 mirror (prefilter_kernel<.., true>), else the fp32 row
+        "algorithmic_bytes_per_launch": rows * (2048 if ", true>" in kern else 4096) + nq * 4096 + nq * k * 12,
     }
     json.dump(doc, open(out_json, "w"), indent=1)
 
