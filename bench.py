@@ -189,6 +189,29 @@ def roofline(rows, nq, k, leg, traffic_doc):
     return out
 
 
+def fp32_rows_leg(corpus, ids, queries, k, dev_index, steps, ref_out, traffic_doc):
+    """The same search over an index WITHOUT the fp16 mirror (CRAG_NO_FP16_MIRROR=1: the prefilter scan streams the
+    4 KiB fp32 rows and rounds them in registers): SURVEY.md 8(d)'s literal accounting, N*D*4 bytes per launch.
+    Results must equal the mirror scan's bit for bit."""
+    from cadence_rag_amd.dense_index import DenseIndex
+    os.environ["CRAG_NO_FP16_MIRROR"] = "1"  # read once, when the index is created
+    try:
+        index = DenseIndex(DIM, capacity=int(corpus.shape[0]), device=dev_index)
+    finally:
+        del os.environ["CRAG_NO_FP16_MIRROR"]
+    try:
+        index.add(corpus, ids)
+        nq = int(queries.shape[0])
+        leg = search_leg(index, queries, k, steps, 20, 3, prewarm_s=0.1)
+        same = all(bool(torch.equal(a, b)) for a, b in zip(leg["out"], ref_out))
+        return {"value": round(nq * steps / leg["times"][0], 2), "unit": "queries/sec",
+                "ms_per_step": round(leg["times"][0] / steps * 1e3, 5), "steps": steps,
+                "results_identical_to_mirror_scan": same,
+                "roofline": roofline(int(corpus.shape[0]), nq, k, leg, traffic_doc)}
+    finally:
+        index.close()
+
+
 def recall_check(corpus_host, queries_host, gpu_ids, k, sample):
     """recall@10 (eval/run_eval.py:52-55) and order identity of the GPU answer vs the fp64 oracle on `sample`."""
     import oracle
@@ -387,6 +410,8 @@ def main() -> None:
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
     ap.add_argument("--encode-steps", type=int, default=20)
+    ap.add_argument("--no-fp32-rows-leg", action="store_true",
+                    help="skip the legs that repeat the search on an index without the fp16 mirror")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -475,9 +500,11 @@ def main() -> None:
         except Exception:
             traffic_doc = None
 
-    overlap = None
+    overlap = fp32_leg = None
     if world == 1:
         overlap = {str(n): overlap_leg(index, queries, k, n, args.steps) for n in (2, 3)}
+        if index.prefilter_row_bytes() == DIM * 2 and not args.no_fp32_rows_leg:
+            fp32_leg = fp32_rows_leg(corpus, ids, queries, k, dev_index, max(200, args.steps // 4), leg["out"], traffic_doc)
     target = None
     if world == 1 and not args.no_target_1m and rows_total == ROWS_CONFIG1:
         gpu_ids_100k = leg["out"][0].cpu().numpy()
@@ -507,6 +534,9 @@ def main() -> None:
                 entry["recall_at_10_vs_fp64_oracle"] = rc
                 entry["topk_order_identical_to_oracle"] = same
                 entry["oracle_sample"] = f"queries {sample} of the step's batch, full {ROWS_CONFIG2}-row fp64 scan each"
+            if big_index.prefilter_row_bytes() == DIM * 2 and not args.no_fp32_rows_leg:
+                entry["fp32_rows_scan"] = fp32_rows_leg(big, None, q64[:qn].contiguous(), k, dev_index, 150, tl["out"],
+                                                        traffic_doc)
             target[name] = entry
         big_index.close()
         del big, big_index
@@ -555,6 +585,8 @@ def main() -> None:
                 "weak scaling: the corpus grows with N, so a flat `value` is ideal; compare `row_queries_per_s`")
         if overlap is not None:
             line["config"]["steps_overlapped_on_streams"] = overlap
+        if fp32_leg is not None:
+            line["fp32_rows_scan"] = fp32_leg
         if target is not None:
             line["target_1m"] = target
         if encode is not None:

@@ -48,7 +48,11 @@ int crag_device_count(void);
 /* ---- corpus: replaces the pgvector `embedding vector(1024)` column + its scan ---------- */
 
 /* Allocate an empty index for up to `capacity` rows of `dim` (<= 1024) floats on `device`.
- * Replaces: the table column + HNSW/seq-scan storage (0001_initial_schema.py:87,98-102). */
+ * Replaces: the table column + HNSW/seq-scan storage (0001_initial_schema.py:87,98-102).
+ * HBM per row: 4 KiB (the fp32 row, source of truth) + 2 KiB (fp16 mirror of the unit row, what the prefilter scan
+ * streams) + 12 bytes.  Environment, read once here: CRAG_NO_FP16_MIRROR=1 leaves the mirror out (the prefilter scan
+ * then streams the fp32 rows: twice the bytes per search, two thirds of the footprint); CRAG_NO_PREFILTER=1 keeps
+ * every search on the exact fp32 MFMA scan.  Results are bit-identical in all three modes. */
 int crag_index_create(int device, int dim, int64_t capacity, crag_index **out);
 int crag_index_destroy(crag_index *ix);
 

@@ -10,7 +10,7 @@ mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
-B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m"
+B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64 -- python3 $R/bench.py $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
