@@ -1991,7 +1991,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 //    x (1/||row|| * 1/||q||), clamp -- so scores and order are bit-identical to the fp32 scan.
 // 3. rank by counting among the exact keys.
 // When the prefilter scan reported an overflow the gated fp32 scan has filled p.partial instead: merge that.
-constexpr int FIN_ROUND = 2048;             // candidates examined per round
+constexpr int FIN_ROUND = 4096;             // candidates examined per round (all of them, for k <= 128 on the bench's corpora)
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
 // One 128-dim slice of the exact dot product: the query slice comes from LDS (fragment order), the row's 32
@@ -2026,7 +2026,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
     __shared__ uint32_t surv[FIN_ROUND];   // rows to rescore in the current round
     __shared__ f32x4 qs[SCAN_WAVES][16][2];  // the query in fragment order: [slice][s][lane half]
     __shared__ int64_t best_id[FIN_BEST];  // external id of best[i]'s row, fetched beside the row itself
-    __shared__ int hist[32];               // exchange buffer of the workgroup reductions
+    __shared__ unsigned long long hist[32];  // exchange buffer of the workgroup reductions
     __shared__ int s_nbest, s_nsurv, s_rescored;
     __shared__ uint32_t s_kth;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -2085,11 +2085,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
             }
             __syncthreads();
         } else {
-            // Binary search on the orderable score: the largest T with at least k candidates >= T, one bit per
-            // round, counting in registers (each thread keeps its <= 8 candidates; beyond FIN_ROUND candidates it
-            // re-reads them) + a wave reduction + one barrier.  The candidates sit just above a common threshold,
-            // so their high bits agree: the search starts below the highest bit in which any two of them differ.
-            // (A radix select with an LDS histogram serialises here: a thousand atomics on ONE bin per pass.)
+            // Search on the orderable score for the largest T with at least k candidates >= T, three bits per round:
+            // every thread counts its candidates (<= 16, in registers; beyond FIN_ROUND candidates it re-reads them)
+            // per value of the next three bits, the seven counts travel packed in two 64-bit words through a wave
+            // reduction and one barrier.  The candidates sit just above a common threshold, so their high bits
+            // agree: the search starts below the highest bit in which any two of them differ.
+            // (A radix select with an LDS histogram serialises here: a thousand atomics on ONE bin per pass; one
+            // bit per round was twenty barriers: 14 us of a top-100 search.)
             constexpr int PER = FIN_ROUND / MERGE_THREADS;
             uint32_t v[PER];
 #pragma unroll
@@ -2097,12 +2099,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
                 const int e = tid + i * MERGE_THREADS;
                 v[i] = (in_lds && e < C) ? lcand[e].x : 0u;
             }
-            auto block_sum = [&](int x, int round) {  // sum over the workgroup; hist[] doubles as the exchange buffer
-                for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-                int *slot = hist + (round & 1) * 8;
-                if ((tid & 63) == 0) slot[tid >> 6] = x;
+            auto block_sum2 = [&](unsigned long long &a, unsigned long long &b, int round) {  // sums over the workgroup
+                for (int o = 32; o > 0; o >>= 1) {
+                    a += (unsigned long long)__shfl_xor((long long)a, o);
+                    b += (unsigned long long)__shfl_xor((long long)b, o);
+                }
+                unsigned long long *slot = hist + (round & 1) * 8;
+                if ((tid & 63) == 0) {
+                    slot[(tid >> 6) * 2] = a;
+                    slot[(tid >> 6) * 2 + 1] = b;
+                }
                 __syncthreads();
-                return slot[0] + slot[1] + slot[2] + slot[3];
+                a = slot[0] + slot[2] + slot[4] + slot[6];
+                b = slot[1] + slot[3] + slot[5] + slot[7];
             };
             uint32_t vmax = 0u, vmin = 0xffffffffu;
             if (in_lds) {
@@ -2125,8 +2134,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
                 vmin = b < vmin ? b : vmin;
             }
             if ((tid & 63) == 0) {
-                hist[16 + (tid >> 6)] = (int)vmax;
-                hist[20 + (tid >> 6)] = (int)vmin;
+                hist[16 + (tid >> 6)] = vmax;
+                hist[20 + (tid >> 6)] = vmin;
             }
             __syncthreads();
             for (int i = 0; i < MERGE_THREADS / 64; ++i) {
@@ -2137,16 +2146,34 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
             const uint32_t diff = vmax ^ vmin;
             const int top = diff ? 32 - __builtin_clz(diff) : 0;       // bits [top, 32) are common to all candidates
             uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
-            for (int bit = top - 1; bit >= 0; --bit) {
-                const uint32_t trial = ans | (1u << bit);
-                int cnt = 0;
+            for (int bit = top, round = 0; bit > 0; ++round) {
+                const int nb = bit >= 3 ? 3 : bit, lo = bit - nb;  // this round decides bits [lo, bit)
+                // digit d of a candidate: 0 if below ans | (1 << lo), else min((v - ans) >> lo, 7); packed counters:
+                // a = #d==1 | #d==2 << 16 | #d==3 << 32 | #d==4 << 48, b = #d==5 | #d==6 << 16 | #d==7 << 32
+                unsigned long long a = 0ull, b = 0ull;
+                auto tally = [&](uint32_t x) {
+                    if (x >= ans) {
+                        const uint32_t d0 = (x - ans) >> lo;
+                        const uint32_t d = d0 > 7u ? 7u : d0;
+                        a += (d >= 1u && d <= 4u) ? 1ull << (16 * (d - 1u)) : 0ull;
+                        b += (d >= 5u) ? 1ull << (16 * (d - 5u)) : 0ull;
+                    }
+                };
                 if (in_lds) {
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) cnt += v[i] >= trial ? 1 : 0;
+                    for (int i = 0; i < PER; ++i) tally(v[i]);
                 } else {
-                    for (int e = tid; e < C; e += MERGE_THREADS) cnt += gcand[e].x >= trial ? 1 : 0;
+                    for (int e = tid; e < C; e += MERGE_THREADS) tally(gcand[e].x);
                 }
-                if (block_sum(cnt, bit) >= k) ans = trial;
+                block_sum2(a, b, round);
+                int at_least = 0;  // candidates whose digit is >= j, j = 7 .. 1
+                uint32_t pick = 0u;
+                for (int j = 7; j >= 1; --j) {
+                    at_least += (int)(((j >= 5 ? b >> (16 * (j - 5)) : a >> (16 * (j - 1)))) & 0xffffull);
+                    if (pick == 0u && at_least >= k && j < (1 << nb)) pick = (uint32_t)j;
+                }
+                ans |= pick << lo;
+                bit = lo;
             }
             if (tid == 0) s_kth = ans;
             __syncthreads();
