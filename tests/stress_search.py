@@ -12,7 +12,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
 t0 = time.time()
 fails = 0
 for case in range(n_cases):
-    n = int(rng.choice([1, 31, 33, 200, 777, 2500, 6000, 20000]))
+    n = int(rng.choice([1, 31, 33, 200, 777, 2500, 6000, 20000, 40000, 66000]))  # the last two: prefilter path
     nq = int(rng.integers(1, 71))
     k = int(rng.choice([1, 5, 10, 31, 32, 33, 50, 64, 65, 100, 128]))
     dim = int(rng.choice([1024, 1024, 1024, 1024, 260, 7]))
