@@ -667,8 +667,10 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const u16 *gu, u16 *out, in
 // ---------------------------------------------------------------------------------------------
 // pooling + final norm + slice + L2 normalise (one block per sequence)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, const u16 *w, const int32_t *cu, float *out,
-                                                             int hidden, int out_dim, int mode, float eps) {
+// `delta` (nullable, mode 0): the last sub-block's output, added to the residual stream for the pooled rows only
+// (bf16 add, as the model's `hidden + mlp(...)`), instead of a pass over every token just to pool one per sequence.
+__global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, const u16 *delta, const u16 *w, const int32_t *cu,
+                                                             float *out, int hidden, int out_dim, int mode, float eps) {
     __shared__ float sh[4];
     __shared__ float row[8192];
     const int b = blockIdx.x;
@@ -679,9 +681,10 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, cons
     }
     if (mode == 0) {  // last token of the residual stream, final RMSNorm applied here
         const u16 *x = hs + (int64_t)(t1 - 1) * hidden;
+        const u16 *dl = delta ? delta + (int64_t)(t1 - 1) * hidden : nullptr;
         float ss = 0.f;
         for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
-            const float v = bf2f(x[i]);
+            const float v = dl ? bf2f(f2bf(bf2f(x[i]) + bf2f(dl[i]))) : bf2f(x[i]);
             row[i] = v;
             ss += v * v;
         }
@@ -797,12 +800,20 @@ int crag_enc_swiglu(const uint16_t *gate_up, uint16_t *out, int64_t rows, int in
 
 int crag_enc_pool_normalize(const uint16_t *hidden_states, const uint16_t *final_norm_w, const int32_t *cu_seqlens,
                             float *out, int n_seqs, int hidden, int out_dim, int mode, float eps, void *stream) {
+    return crag_enc_pool_normalize_add(hidden_states, nullptr, final_norm_w, cu_seqlens, out, n_seqs, hidden, out_dim,
+                                       mode, eps, stream);
+}
+
+int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *delta, const uint16_t *final_norm_w,
+                                const int32_t *cu_seqlens, float *out, int n_seqs, int hidden, int out_dim, int mode,
+                                float eps, void *stream) {
     if (!hidden_states || !cu_seqlens || !out) return efail("pool_normalize: NULL pointer");
     if (mode == 0 && !final_norm_w) return efail("pool_normalize: last-token mode needs the final norm weight");
+    if (delta && mode != 0) return efail("pool_normalize: a delta is only added in last-token mode");
     if (hidden <= 0 || hidden > 8192 || out_dim <= 0 || out_dim > hidden) return efail("pool_normalize: bad sizes");
     if (n_seqs <= 0) return 0;
     hipLaunchKernelGGL(pool_normalize_kernel, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, hidden_states,
-                       final_norm_w, cu_seqlens, out, hidden, out_dim, mode, eps);
+                       delta, final_norm_w, cu_seqlens, out, hidden, out_dim, mode, eps);
     return hip_ok("pool_normalize");
 }
 

@@ -67,9 +67,13 @@ def swiglu(gate_up, out):
     return out
 
 
-def pool_normalize(hidden_states, final_norm_w, cu, out, out_dim: int, mode: int, eps: float):
+def pool_normalize(hidden_states, final_norm_w, cu, out, out_dim: int, mode: int, eps: float, delta=None):
     _req(hidden_states, torch.bfloat16, "hidden_states"); _req(out, torch.float32, "out")
-    _native.check(_native.load().crag_enc_pool_normalize(_p(hidden_states), _p(final_norm_w), _p(cu), _p(out),
-                                                         cu.numel() - 1, hidden_states.shape[1], out_dim, mode,
-                                                         float(eps), _stream()), "crag_enc_pool_normalize")
+    if delta is not None:
+        _req(delta, torch.bfloat16, "delta")
+        if delta.shape != hidden_states.shape:
+            raise ValueError("delta must have the shape of hidden_states")
+    _native.check(_native.load().crag_enc_pool_normalize_add(_p(hidden_states), _p(delta), _p(final_norm_w), _p(cu),
+                                                             _p(out), cu.numel() - 1, hidden_states.shape[1], out_dim,
+                                                             mode, float(eps), _stream()), "crag_enc_pool_normalize")
     return out

@@ -241,10 +241,8 @@ class Qwen3Encoder:
             delta = F.linear(act, L["down"])
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
         if c.pooling == "last":
-            # residual + last delta for the pooled rows only, then the final norm inside the pool kernel
-            final = torch.empty_like(x)
-            torch.add(resid, delta, out=final)
-            ops.pool_normalize(final, self.final_norm, batch.cu, out, c.out_dim, 0, c.rms_norm_eps)
+            # residual + last delta and the final norm for the pooled rows only, inside the pool kernel
+            ops.pool_normalize(resid, self.final_norm, batch.cu, out, c.out_dim, 0, c.rms_norm_eps, delta=delta)
         elif c.pooling == "mean":
             ops.rmsnorm(delta, self.final_norm, normed, c.rms_norm_eps, residual_in=resid, residual_out=None)
             ops.pool_normalize(normed, None, batch.cu, out, c.out_dim, 1, c.rms_norm_eps)

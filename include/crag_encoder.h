@@ -68,6 +68,12 @@ int crag_enc_swiglu(const uint16_t *gate_up, uint16_t *out, int64_t rows, int in
 int crag_enc_pool_normalize(const uint16_t *hidden_states, const uint16_t *final_norm_w,
                             const int32_t *cu_seqlens, float *out, int n_seqs, int hidden, int out_dim,
                             int mode, float eps, void *stream);
+/* Same, with the last sub-block's output `delta` (nullable; mode 0 only) added to the residual stream for the
+ * pooled rows only: hidden = bf16(hidden_states + delta) -- the model's final `hidden + mlp(...)` without a pass
+ * over every token. */
+int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *delta, const uint16_t *final_norm_w,
+                                const int32_t *cu_seqlens, float *out, int n_seqs, int hidden, int out_dim,
+                                int mode, float eps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -191,6 +191,23 @@ def test_pool_normalize(gpu, mode):
     assert torch.allclose(out.norm(dim=1), torch.ones(3, device=DEV), atol=1e-5)
 
 
+def test_pool_normalize_adds_the_last_delta_for_the_pooled_rows(gpu):
+    """Last-token pooling with the final residual add folded in: the same bits as adding over every token first."""
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(6)
+    hs = _bf(torch.randn(14, 256, generator=g))
+    delta = _bf(0.3 * torch.randn(14, 256, generator=g))
+    w = _bf(1 + 0.1 * torch.randn(256, generator=g))
+    cu = torch.tensor([0, 3, 4, 14], dtype=torch.int32, device=DEV)
+    fused = torch.empty(3, 64, dtype=torch.float32, device=DEV)
+    plain = torch.empty(3, 64, dtype=torch.float32, device=DEV)
+    ops.pool_normalize(hs, w, cu, fused, 64, 0, 1e-6, delta=delta)
+    ops.pool_normalize(hs + delta, w, cu, plain, 64, 0, 1e-6)   # torch's bf16 add over all tokens
+    assert torch.equal(fused, plain)
+    with pytest.raises(Exception):
+        ops.pool_normalize(hs, None, cu, fused, 64, 1, 1e-6, delta=delta)
+
+
 def _tiny_hf_and_mine(pooling="last"):
     from transformers import Qwen3Config as HFConfig
     from transformers.models.qwen3.modeling_qwen3 import Qwen3Model
