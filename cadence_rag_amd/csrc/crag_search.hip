@@ -1967,15 +1967,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         }
         inv_cur = inv_nxt;
     }
-    if (c.n_tiles > 0) {  // the first tile against the final bounds
+    if (c.n_tiles > 0) {  // the first two tiles, against the bounds the wave holds now
         if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
-        uint32_t gb[RPO][SETS];
-        load_bounds(gb);
-        derive(gb);
+        // (a last read of the shared maxima would pass ~4 rows per query fewer of these 64 rows x 256 workgroups
+        // and cost every workgroup a device-coherent load + sort at its very end: only a wave without any bound
+        // asks)
+        bool none = false;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) none = none || (((o.okmask >> e) & 1u) && tau[e] == 0u);
+        if (__builtin_amdgcn_ballot_w64(none) != 0ull) {
+            uint32_t gb[RPO][SETS];
+            load_bounds(gb);
+            derive(gb);
+        }
         bool pass[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
         pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
+        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
 #pragma unroll
         for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e];
         pf_stage<NQB>(L, o, stash2, pass, stash2_row, p.flags);
