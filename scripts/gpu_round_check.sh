@@ -10,6 +10,8 @@ mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
+# the headline leg alone (in the full command above the 1M legs launch the same kernel template)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -- python3 $R/bench.py --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg > /dev/null 2> $O/stats_headline.err
 B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64 -- python3 $R/bench.py $B > /dev/null 2>&1
@@ -20,6 +22,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
 cd $R
 python scripts/pmc_summary.py stats $O/stats $O/${RN}_bench_kernel_stats.csv
+python scripts/pmc_summary.py stats $O/stats_headline $O/${RN}_headline_leg_kernel_stats.csv
 for w in 100k64 1m32 1m64; do
   for c in FETCH_SIZE WRITE_SIZE; do python scripts/pmc_summary.py pmc $O/pmc_${c}_$w $O/${RN}_pmc_${c}_$w.csv; done
 done
@@ -29,6 +32,6 @@ python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_100k64.csv $O/${RN
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m32.csv $O/${RN}_pmc_WRITE_SIZE_1m32.csv 1000000x32x10 $O/traffic.json
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m64.csv $O/${RN}_pmc_WRITE_SIZE_1m64.csv 1000000x64x10 $O/traffic.json
 # raw traces are large: keep only summaries
-rm -rf $O/pmc_* $O/stats
+rm -rf $O/pmc_* $O/stats $O/stats_headline
 cat $O/traffic.json
 head -14 $O/${RN}_bench_kernel_stats.csv | cut -c1-160
