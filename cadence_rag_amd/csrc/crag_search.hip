@@ -25,6 +25,11 @@
 // registers as half-wave (32-lane) sorted lists, updated with a bitonic sort/merge built on
 // ds_swizzle.  Each workgroup writes its per-query top-k; merge_partials_kernel selects the
 // final top-k (threshold pruning + rank-by-counting, radix select as the bounded fallback).
+//
+// These exact fp32 MFMA scans serve small corpora, rows with extreme norms and the overflow fallback.  From
+// 128 rows per workgroup on, a search takes the prefilter path in the second half of this file: an fp16 MFMA
+// scan over the fp16 mirror of the unit rows with a proven error bound, then exact fp32 rescoring of the few
+// survivors from the fp32 rows (prefilter_kernel / finalize_kernel) -- same bits out, half the bytes in.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1525,13 +1530,15 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // Prefilter path: fp16 MFMA scan (HBM-bound for any batch) + exact fp32 rescoring of the survivors
 // ==========================================================================================
 // The fp32 MFMA runs at 1/16 of the fp16 rate, which makes a 64-query pass matrix-pipe bound (4.2).  Here
-// the corpus is streamed ONCE, every fp32 fragment is normalised (x 1/||row||) and rounded to fp16 in
-// registers and multiplied with the fp16 unit queries by v_mfma_f32_32x32x16_f16.  The result is the cosine
-// up to a PROVEN bound delta (rounding both operands to 11 significant bits + fp32 accumulation, see
-// PF_DELTA); a row whose approximate score is within 2*delta of a lower bound on the k-th best approximate
-// score may be in the exact top-k and becomes a candidate, every other row cannot.  finalize_kernel rescoring
-// the (few) candidates with the fixed-order fp32 chain of the scan kernels above gives bit-identical scores
-// and order.  Bytes: the same N*D*4 corpus stream + 4 KiB per rescored row (reported by bench.py).
+// the corpus is streamed ONCE as unit rows rounded to fp16 -- read ready-made from the fp16 mirror that
+// store_rows_kernel keeps beside the fp32 rows (2 KiB per row), or, for an index without the mirror, converted in
+// registers from the fp32 rows (x 1/||row||, v_cvt_pk_f16_f32: the same bits) -- and multiplied with the fp16
+// unit queries by v_mfma_f32_32x32x16_f16.  The result is the cosine up to a PROVEN bound delta (rounding both
+// operands to 11 significant bits + fp32 accumulation, see PF_DELTA); a row whose approximate score is within
+// 2*delta of a lower bound on the k-th best approximate score may be in the exact top-k and becomes a
+// candidate, every other row cannot.  finalize_kernel rescoring the (few) candidates from the fp32 rows with the
+// fixed-order fp32 chain of the scan kernels above gives bit-identical scores and order.  Bytes: N*D*2 (mirror)
+// or N*D*4 (fp32 rows) of corpus stream + 4 KiB per rescored row (reported by bench.py).
 //
 // Lower bound on the k-th best approximate score of a query without any sorted list: rows are split into
 // 32*sets classes (row position mod 32 = the lane that owns the row, x tile index mod sets); gbound[q][class]
