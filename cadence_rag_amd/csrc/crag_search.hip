@@ -2011,8 +2011,8 @@ constexpr int FIN_ROUND = 4096;             // candidates examined per round (al
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
 // One 128-dim slice of the exact dot product: the query slice comes from LDS (fragment order), the row's 32
-// float4 are fetched first, all of them (32 independent 16-byte loads in flight: the row is scattered over 256
-// cache lines in the tile32 layout, latency is everything here), then the fmaf chain runs in the scan's k order:
+// float4 are fetched first, all of them (32 independent 16-byte loads in flight, four per 64-byte piece of the
+// row: latency is everything here), then the fmaf chain runs in the scan's k order:
 // s = 0..15, then component, then lane half (k = 0, 1 of one 32x32x2 MFMA).
 __device__ __forceinline__ float exact_slice_dot(const f32x4 *qslice /* [16][2] float4 in LDS */,
                                                  const f32x4 *ctile /* tile base + slice */, int jrow) {
