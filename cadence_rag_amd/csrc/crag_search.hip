@@ -1640,6 +1640,7 @@ struct PfLds {
     uint2 stage[PF_STAGE];                       // staged candidates: x = orderable score, y = (row - window) << 6 | query
     uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
     uint32_t n_stage;
+    uint32_t want_flush[2][SCAN_WAVES];          // [slab buffer][wave]: the wave saw the staging buffer fill up
 };
 
 // What a wave owns after the split-K reduction: RPO = 2*NQB queries per lane (row j = lane & 31), consecutive
@@ -1893,7 +1894,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) v[e] = acc[(ow * RPO + e) >> 4][(ow * RPO + e) & 15];
             L.slab[buf][ow][w][lane] = v;
         }
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        // One barrier per tile.  It also carries the (uniform) decision to flush the staging buffer: every wave
+        // posts what it saw after its own appends of the previous tile -- the wave whose append came last saw the
+        // final count -- and all waves OR the same eight words behind the barrier.  [__syncthreads_or is a
+        // workgroup reduction with three barriers of its own.]
+        if (lane == 0) L.want_flush[buf][w] = L.n_stage > (uint32_t)PF_FLUSH_ABOVE ? 1u : 0u;
+        __syncthreads();
+        {
+            const u32x4 f0 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][0]);
+            const u32x4 f1 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][4]);
+            if ((f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0u) pf_flush<NQB>(p, L, c.t_begin * 32);
+        }
         float sc[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) sc[e] = 0.f;
