@@ -105,6 +105,8 @@ struct crag_index {
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
     bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false;
+    int env_pf_nt = -1;                       // CRAG_PF_NT=0/1 forces the cache policy of the prefilter scan (developer switch)
+    int64_t nt_above_bytes = 1536ll << 20;     // mirror bytes above which its loads stream (measured: no gain below ~1 GB)
     // a stored row whose norm lies outside [1e-30, 1e30]: the fp16 prefilter's error bound assumes normalised
     // rows in fp32's comfortable range, so such an index always takes the plain fp32 scan
     bool irregular = false;
@@ -296,6 +298,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.reverse = sp.reverse;
         fp.sets = k <= 24 ? 1 : (k <= 48 ? 2 : 4);
         fp.cap = cap;
+        {   // streaming cache policy for a mirror far larger than the Infinity Cache (see prefilter_kernel)
+            const int64_t streamed = ix->size * (int64_t)crag::DIM * 2;
+            fp.nt = !ix->corpus16 ? 0 : (ix->env_pf_nt >= 0 ? ix->env_pf_nt : (streamed > ix->nt_above_bytes ? 1 : 0));
+        }
         const int nqb = wide ? 2 : 1;
         HIP_TRY(crag::launch_prefilter(fp, nqb, nq_pad / (32 * nqb), st, &ix->last_scan_kernel));
         if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
@@ -414,6 +420,8 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_reverse = getenv("CRAG_NO_REVERSE") != nullptr;
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
+    if (const char *v = getenv("CRAG_PF_NT")) ix->env_pf_nt = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
         // + 2 KiB per row beside the 4 KiB fp32 row: the prefilter scan then streams half the bytes.  Padding rows
         // read as zeros (their positions are beyond every workgroup's row range anyway).

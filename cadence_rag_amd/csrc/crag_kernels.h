@@ -82,6 +82,7 @@ struct PfParams {
     int64_t n_rows;
     int nq, k, G, reverse;
     int sets;                 // 1, 2 or 4 class sets (<= k)
+    int nt;                   // corpus loads with the streaming cache policy (corpus larger than the Infinity Cache)
     int cap;
 };
 

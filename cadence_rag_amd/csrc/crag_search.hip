@@ -1717,9 +1717,16 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
 // stalled wave stalls its workgroup at the next barrier, and while bounds are young some wave of every workgroup
 // lifts a class maximum on nearly every tile.  Plain stores instead of atomics ran at 78 / 626 us but lose
 // maxima (20x the candidates); eight copies of the cells (one per XCD) weaken the bound 10x for no gain.]
-template <int NQB, int SETS, bool MIRROR>
+template <int NQB, int SETS, bool MIRROR, bool NT>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB;
+    // Cache policy of the corpus loads: NT = streaming ("slc" / nt: the lines are not kept) for a mirror far larger
+    // than the 256 MB Infinity Cache -- 1M rows x 64: 4-9 % faster (348 -> 335 us on one box, 340 -> 310 on another).
+    // Up to 500 000 rows it makes no difference or hurts: a 100 000-row mirror (205 MB) stays cached between
+    // searches (the passes alternate direction) and is 3 us FASTER with plain loads.  Never for the scan of the
+    // fp32 rows, whose load instructions each use half of the lines they touch and count on finding the other
+    // half cached (83 vs 71 us at 100 000 rows, 705 vs 660 us at 1M).
+    constexpr int AUX = NT ? 2 : 0;
     __shared__ PfLds<NQB> L;
     ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
     {   // whole tiles per workgroup
@@ -1766,7 +1773,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     {
         const uint32_t v0 = voff(0);
 #pragma unroll
-        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (MIRROR ? (uint32_t)s * 1024u : b_soff(s)), 0, 0);
+        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (MIRROR ? (uint32_t)s * 1024u : b_soff(s)), 0, AUX);
     }
     // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
     // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
@@ -1878,12 +1885,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
-                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qb][t8], bf, t8 == 0 ? zero16 : acc[qb], 0, 0, 0);
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[qb][t8], bf, t8 == 0 ? zero16 : acc[qb], 0, 0, AUX);
             if constexpr (MIRROR) {
-                b[t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + t8 * 1024, 0, 0);
+                b[t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + t8 * 1024, 0, AUX);
             } else {
-                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8), 0, 0);
-                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8 + 1), 0, 0);
+                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8), 0, AUX);
+                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8 + 1), 0, AUX);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -2363,10 +2370,11 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
         hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, st, p);     \
     } while (0)
     const bool mirror = p.corpus16 != nullptr;
-#define CRAG_PICK(NQB_, SETS_)                                       \
-    do {                                                              \
-        if (mirror) CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, true>); \
-        else CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, false>);       \
+#define CRAG_PICK(NQB_, SETS_)                                                      \
+    do {                                                                             \
+        if (mirror && p.nt) CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, true, true>);   \
+        else if (mirror) CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, true, false>);     \
+        else CRAG_LAUNCH(prefilter_kernel<NQB_, SETS_, false, false>);                \
     } while (0)
     if (nqb == 2) {
         if (p.sets == 1) CRAG_PICK(2, 1);

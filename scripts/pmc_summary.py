@@ -14,6 +14,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 from collections import defaultdict
@@ -76,8 +77,9 @@ def traffic(fetch_csv: str, write_csv: str, workload: str, out_json: str) -> Non
         "FETCH_SIZE_KB": fetch_kb,
         "WRITE_SIZE_KB": write_kb,
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + (write_kb or 0.0) * 1024),
-        # bytes of a row the scan streams: 2 KiB from the fp16 mirror (prefilter_kernel<.., true>), else the fp32 row
-        "algorithmic_bytes_per_launch": rows * (2048 if ", true>" in kern else 4096) + nq * 4096 + nq * k * 12,
+        # bytes of a row the scan streams: 2 KiB from the fp16 mirror (prefilter_kernel<NQB, SETS, true, ..>), else the fp32 row
+        "algorithmic_bytes_per_launch": rows * (2048 if re.search(r"prefilter_kernel<\d+, \d+, true", kern) else 4096)
+                                        + nq * 4096 + nq * k * 12,
     }
     json.dump(doc, open(out_json, "w"), indent=1)
 
