@@ -52,7 +52,9 @@ int crag_device_count(void);
  * HBM per row: 4 KiB (the fp32 row, source of truth) + 2 KiB (fp16 mirror of the unit row, what the prefilter scan
  * streams) + 12 bytes.  Environment, read once here: CRAG_NO_FP16_MIRROR=1 leaves the mirror out (the prefilter scan
  * then streams the fp32 rows: twice the bytes per search, two thirds of the footprint); CRAG_NO_PREFILTER=1 keeps
- * every search on the exact fp32 MFMA scan.  Results are bit-identical in all three modes. */
+ * every search on the exact fp32 MFMA scan.  Results are bit-identical in all three modes.  (Developer switches,
+ * same place: CRAG_PF_NT=0/1 and CRAG_PF_NT_ABOVE_MB=<n> override when the mirror scan uses the streaming cache
+ * policy -- by default for mirrors above 1.5 GB.) */
 int crag_index_create(int device, int dim, int64_t capacity, crag_index **out);
 int crag_index_destroy(crag_index *ix);
 
