@@ -57,6 +57,29 @@ def test_fp16_mirror_scan_equals_the_scan_of_the_fp32_rows(gpu, monkeypatch):
     assert_topk_matches(out[True][1][0][:3], out[True][1][1][:3], out[True][1][2][:3], *want, tol=TOL)
 
 
+@pytest.mark.parametrize("nq,k", [(64, 10), (20, 40), (64, 100)])
+def test_streaming_cache_policy_changes_nothing_but_the_loads(gpu, monkeypatch, nq, k):
+    """Mirrors above 1.5 GB are scanned with non-temporal loads (another template instance of the kernel); forced
+    here on a small corpus: same results, and the kernel name says which instance ran."""
+    rng = np.random.default_rng(300 + nq + k)
+    corpus = unit_rows(rng, 40_000)
+    q = rng.standard_normal((nq, 1024)).astype(np.float32)
+    out = {}
+    for nt in ("0", "1"):
+        monkeypatch.setenv("CRAG_PF_NT", nt)
+        ix = _index(corpus, monkeypatch)
+        try:
+            out[nt] = ix.search(q, k)
+            assert ix.last_scan_kernel().endswith("true, true>" if nt == "1" else "true, false>"), ix.last_scan_kernel()
+        finally:
+            ix.close()
+    monkeypatch.delenv("CRAG_PF_NT")
+    for a, b in zip(out["0"], out["1"]):
+        assert np.array_equal(a, b, equal_nan=True)
+    want = oracle.exact_topk(q[:3], corpus, k, mode=oracle.F64, fast=True)
+    assert_topk_matches(out["1"][0][:3], out["1"][1][:3], out["1"][2][:3], *want, tol=TOL)
+
+
 def _both(corpus, q, k, monkeypatch, mask=None):
     packed = None if mask is None else DenseIndex.pack_mask(mask)
     out = []
