@@ -328,7 +328,9 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int):
         dt = float(t.item())
     tokens = int(lens.sum())
     ctx = float((lens.astype(float) ** 2).sum() / lens.sum())
-    tflops = cfg.flops_per_token(ctx) * tokens * steps / dt / 1e12
+    tflops = cfg.flops_per_token(ctx) * tokens * steps / dt / 1e12   # tokens/s x FLOPs per token of the model
+    # executed: minus the last layer's o / MLP projections of the rows that are not pooled (last-token pooling)
+    tflops_exec = (cfg.flops_per_token(ctx) * tokens - cfg.flops_skipped_in_last_layer(tokens, n_chunks)) * steps / dt / 1e12
     ok = bool(torch.isfinite(out).all().item()) and bool(torch.allclose(out.norm(dim=1), torch.ones(n_chunks, device=dev), atol=1e-3))
     res = {
         "metric": "chunks embedded/sec", "value": round(world * n_chunks * steps / dt, 2), "unit": "chunks/sec",
@@ -340,7 +342,11 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int):
         # per GPU: `tflops` is this rank's own batch over the slowest rank's time
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": round(tflops / 2500.0, 4), "traffic": None,
-                     "note": "per GPU; whole forward (library GEMMs + HIP ops), algorithmic FLOPs 2*P + causal attention"},
+                     "executed_tflops": round(tflops_exec, 1), "executed_frac": round(tflops_exec / 2500.0, 4),
+                     "note": "per GPU; whole forward (library GEMMs + HIP ops); achieved = SURVEY 8(d)'s algorithmic "
+                             "FLOPs (2*P + causal attention per token of the model) / time; executed_* leaves out "
+                             "the last layer's o / MLP projections of the non-pooled rows, which last-token pooling "
+                             "never needs and the forward does not compute"},
     }
     if rank == 0:
         try:

@@ -16,6 +16,7 @@ position is always the last real token.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -59,6 +60,13 @@ class Qwen3Config:
         attn = 4.0 * (avg_context / 2.0) * self.head_dim * self.num_heads
         return self.num_layers * (2.0 * per_layer + attn)
 
+    def flops_skipped_in_last_layer(self, n_tokens: int, n_seqs: int) -> float:
+        """With last-token pooling the last layer's output projection and MLP run on the pooled rows only
+        (Qwen3Encoder.forward_packed): FLOPs of the full-model count that are NOT executed."""
+        if self.pooling != "last":
+            return 0.0
+        return 2.0 * (self.q_size * self.hidden_size + 3 * self.hidden_size * self.intermediate_size) * max(n_tokens - n_seqs, 0)
+
 
 @dataclass
 class PackedBatch:
@@ -72,6 +80,8 @@ class PackedBatch:
     tok_of_pad: torch.Tensor  # int32 [t_pad]
     blk_seq: torch.Tensor     # int32 [n_blocks]
     blk_q0: torch.Tensor      # int32 [n_blocks]
+    last_tok: torch.Tensor    # int64 [B]: packed position of every sequence's last token
+    cu_one: torch.Tensor      # int32 [B+1] = 0..B: the batch of last tokens as B one-token sequences
 
     @staticmethod
     def build(lengths: Sequence[int], device) -> "PackedBatch":
@@ -97,8 +107,9 @@ class PackedBatch:
         def dev(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)
 
+        last_tok = torch.from_numpy(np.ascontiguousarray(cu[1:] - 1)).to(device, non_blocking=True)
         return PackedBatch(t, int(lens.size), t_pad, dev(cu), dev(cu_pad), dev(positions), dev(tok_of_pad),
-                           dev(blk_seq[order]), dev(blk_q0[order]))
+                           dev(blk_seq[order]), dev(blk_q0[order]), last_tok, dev(np.arange(lens.size + 1)))
 
 
 QKV_ROW_CHUNK = 32768
@@ -217,6 +228,7 @@ class Qwen3Encoder:
         attn = torch.empty(t, c.q_size, dtype=bf, device=dev)
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
+        last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -234,6 +246,21 @@ class Qwen3Encoder:
             ops.v_transpose(qkv_buf, vt, batch.tok_of_pad, c.num_heads, c.num_kv_heads)
             ops.attention(qkv_buf, vt, attn, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0,
                           c.num_heads, c.num_kv_heads, scale)
+            if last_only and i == len(self.layers) - 1:
+                # Last layer, last-token pooling: behind the attention only the B pooled rows matter (no later
+                # layer reads the other tokens' hidden states), so the output projection, the second norm and the
+                # whole MLP run on B rows instead of T: one layer's worth of o / gate|up / down GEMMs less.
+                attn_l = attn.index_select(0, batch.last_tok)
+                resid_l = resid.index_select(0, batch.last_tok)
+                delta_l = F.linear(attn_l, L["o"])
+                normed_l = torch.empty_like(resid_l)
+                ops.rmsnorm(delta_l, L["ln2"], normed_l, c.rms_norm_eps, residual_in=resid_l, residual_out=resid_l)
+                act_l = torch.empty(batch.n_seqs, c.intermediate_size, dtype=bf, device=dev)
+                ops.swiglu(F.linear(normed_l, L["gate_up"]), act_l)
+                delta_l = F.linear(act_l, L["down"])
+                out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
+                ops.pool_normalize(resid_l, self.final_norm, batch.cu_one, out, c.out_dim, 0, c.rms_norm_eps, delta=delta_l)
+                return out
             delta = F.linear(attn, L["o"])
             ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             gate_up = F.linear(normed, L["gate_up"])

@@ -261,6 +261,24 @@ def test_full_forward_matches_transformers_qwen3(gpu, pooling):
     assert diff.max() < 1e-2
 
 
+def test_last_layer_on_pooled_rows_only_equals_the_full_last_layer(gpu, monkeypatch):
+    """Last-token pooling: the last layer's output projection and MLP run on the pooled rows only.  Same math;
+    the GEMMs of B rows and of T rows may round the last bf16 bit differently (other tile shapes)."""
+    model, enc, cfg = _tiny_hf_and_mine("last")
+    rng = np.random.default_rng(17)
+    token_lists = [rng.integers(0, 503, size=n).tolist() for n in (1, 2, 31, 32, 33, 100, 257, 64)]
+    short = enc.embed_token_lists(token_lists)
+    monkeypatch.setenv("CRAG_ENC_FULL_LAST_LAYER", "1")
+    full = enc.embed_token_lists(token_lists)
+    monkeypatch.delenv("CRAG_ENC_FULL_LAST_LAYER")
+    diff = (short - full).abs()
+    print(f"\nlast layer on pooled rows vs full: max |d| = {diff.max():.2e}")
+    assert diff.max() < 2e-3            # a bf16 ulp or two of an element of magnitude 1/8
+    assert ((short * full).sum(-1)).min() > 0.99999
+    want = _hf_embed(model, cfg, token_lists, "last")
+    assert ((short.cpu() * want).sum(-1)).min() > 0.9995
+
+
 def test_packed_batch_equals_one_by_one_and_encoder_protocol(gpu, monkeypatch):
     from cadence_rag_amd import embeddings
     from cadence_rag_amd.config import settings
