@@ -646,21 +646,37 @@ void attention_pair_kernel(AttnParams p) {
 // SwiGLU
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swiglu_kernel(const u16 *gu, u16 *out, int64_t rows, int inter) {
+    // one row per block trip, 16-byte chunks across the threads: no index division, all loads of a trip in flight
     const int chunks = inter >> 3;
-    const int64_t total = rows * chunks;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / chunks;
-        const int c = (int)(i - r * chunks);
-        const Pack8 g = reinterpret_cast<const Pack8 *>(gu + r * 2 * inter)[c];
-        const Pack8 u = reinterpret_cast<const Pack8 *>(gu + r * 2 * inter + inter)[c];
-        Pack8 o;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const Pack8 *gp = reinterpret_cast<const Pack8 *>(gu + r * 2 * inter);
+        const Pack8 *up = reinterpret_cast<const Pack8 *>(gu + r * 2 * inter + inter);
+        Pack8 *op = reinterpret_cast<Pack8 *>(out + r * inter);
+        for (int c0 = threadIdx.x; c0 < chunks; c0 += 4 * 256) {
+            Pack8 g[4], u[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = bf2f(g.v[e]);
-            const float act = bf2f(f2bf(x / (1.f + __expf(-x))));  // silu in fp32, rounded to bf16 like the model
-            o.v[e] = f2bf(act * bf2f(u.v[e]));
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q * 256;
+                if (c < chunks) {
+                    g[q] = gp[c];
+                    u[q] = up[c];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c0 + q * 256;
+                if (c < chunks) {
+                    Pack8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = bf2f(g[q].v[e]);
+                        const float act = bf2f(f2bf(x / (1.f + __expf(-x))));  // silu in fp32, rounded to bf16 like the model
+                        o.v[e] = f2bf(act * bf2f(u[q].v[e]));
+                    }
+                    op[c] = o;
+                }
+            }
         }
-        reinterpret_cast<Pack8 *>(out + r * inter)[c] = o;
     }
 }
 
@@ -792,8 +808,7 @@ int crag_enc_swiglu(const uint16_t *gate_up, uint16_t *out, int64_t rows, int in
     if (!gate_up || !out) return efail("swiglu: NULL pointer");
     if (inter <= 0 || (inter & 7)) return efail("swiglu: inter must be a positive multiple of 8");
     if (rows <= 0) return 0;
-    const int64_t total = rows * (inter >> 3);
-    const unsigned grid = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    const unsigned grid = (unsigned)(rows < 65536 * 16 ? rows : 65536 * 16);
     hipLaunchKernelGGL(swiglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gate_up, out, rows, inter);
     return hip_ok("swiglu");
 }
