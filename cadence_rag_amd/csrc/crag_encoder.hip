@@ -145,43 +145,53 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const u16 *x, con
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16 *qkv, const u16 *qw, const u16 *kw,
                                                            const float *cos_sin, const int32_t *positions,
                                                            int64_t n_tokens, int hq, int hkv, float eps) {
+    // One block trip = one token: group g (16 lanes) walks the head vectors g, g + 16, g + 32, ... of the token with
+    // the token's cos/sin chunk and the norm weights in registers (loaded per head vector they were 64 B of table
+    // reads per 16 B of q/k: twice the data traffic, from the caches).
     const int heads = hq + hkv;  // q heads then k heads are contiguous in the row
     const int64_t row_stride = (int64_t)(hq + 2 * hkv) * CRAG_HEAD_DIM;
-    const int64_t vec = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // head-vector index
-    const int sub = threadIdx.x & 15;                                   // 8-element chunk of the head
-    if (vec >= n_tokens * heads) return;
-    const int64_t t = vec / heads;
-    const int hd = (int)(vec - t * heads);
-    u16 *p = qkv + t * row_stride + (int64_t)hd * CRAG_HEAD_DIM + sub * 8;
-    const u16 *wn = (hd < hq ? qw : kw) + sub * 8;
-    Pack8 a = *reinterpret_cast<Pack8 *>(p);
-    const Pack8 w8 = *reinterpret_cast<const Pack8 *>(wn);
-    float v[8];
-    float ss = 0.f;
+    const int g = threadIdx.x >> 4;
+    const int sub = threadIdx.x & 15;  // 8-element chunk of the head
+    const bool first_half = sub < 8;   // elements [0, 64): out = x*cos - x[i+64]*sin ; else x*cos + x[i-64]*sin
+    const Pack8 wq8 = *reinterpret_cast<const Pack8 *>(qw + sub * 8);
+    const Pack8 wk8 = *reinterpret_cast<const Pack8 *>(kw + sub * 8);
+    for (int64_t t = blockIdx.x; t < n_tokens; t += gridDim.x) {
+        const int pos = positions[t];
+        const float *cs = cos_sin + ((int64_t)pos * 64 + (sub & 7) * 8) * 2;
+        float c[8], sn[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        v[e] = bf2f(a.v[e]);
-        ss += v[e] * v[e];
+        for (int e = 0; e < 8; ++e) {  // the model casts cos/sin to bf16
+            c[e] = bf2f(f2bf(cs[2 * e]));
+            sn[e] = bf2f(f2bf(cs[2 * e + 1]));
+        }
+        for (int hd = g; hd < heads; hd += 16) {
+            u16 *p = qkv + t * row_stride + (int64_t)hd * CRAG_HEAD_DIM + sub * 8;
+            const Pack8 a = *reinterpret_cast<Pack8 *>(p);
+            const Pack8 &w8 = hd < hq ? wq8 : wk8;
+            float v[8];
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = bf2f(a.v[e]);
+                ss += v[e] * v[e];
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);  // 16-lane group
+            const float rstd = rsqrtf(ss / (float)CRAG_HEAD_DIM + eps);
+            float n[8], partner[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) n[e] = bf2f(f2bf(bf2f(w8.v[e]) * bf2f(f2bf(v[e] * rstd))));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) partner[e] = __shfl_xor(n[e], 8);  // rotate_half: element i <-> i + 64
+            Pack8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float rot = first_half ? -partner[e] : partner[e];
+                o.v[e] = f2bf(n[e] * c[e] + rot * sn[e]);
+            }
+            *reinterpret_cast<Pack8 *>(p) = o;
+        }
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o);  // 16-lane group
-    const float rstd = rsqrtf(ss / (float)CRAG_HEAD_DIM + eps);
-    float n[8], partner[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) n[e] = bf2f(f2bf(bf2f(w8.v[e]) * bf2f(f2bf(v[e] * rstd))));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) partner[e] = __shfl_xor(n[e], 8);
-    const int pos = positions[t];
-    const float *cs = cos_sin + ((int64_t)pos * 64 + (sub & 7) * 8) * 2;
-    const bool first_half = sub < 8;  // elements [0, 64): out = x*cos - x[i+64]*sin ; else x*cos + x[i-64]*sin
-    Pack8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float c = bf2f(f2bf(cs[2 * e])), s = bf2f(f2bf(cs[2 * e + 1]));  // the model casts cos/sin to bf16
-        const float rot = first_half ? -partner[e] : partner[e];
-        o.v[e] = f2bf(n[e] * c + rot * s);
-    }
-    *reinterpret_cast<Pack8 *>(p) = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -756,8 +766,8 @@ int crag_enc_qk_norm_rope(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_
     if (!qkv || !q_norm_w || !k_norm_w || !cos_sin || !positions) return efail("qk_norm_rope: NULL pointer");
     if (hq <= 0 || hkv <= 0) return efail("qk_norm_rope: bad head counts");
     if (n_tokens <= 0) return 0;
-    const int64_t vecs = n_tokens * (hq + hkv);
-    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((vecs + 15) / 16)), dim3(256), 0, (hipStream_t)stream, qkv,
+    const unsigned grid = (unsigned)(n_tokens < 65536 * 16 ? n_tokens : 65536 * 16);
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv,
                        q_norm_w, k_norm_w, cos_sin, positions, n_tokens, hq, hkv, eps);
     return hip_ok("qk_norm_rope");
 }
