@@ -44,6 +44,8 @@ SIGNATURES = {
     "crag_index_profile_enable": (_c.c_int, [_P, _c.c_int]),
     "crag_index_profile_read": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double),
                                            _c.POINTER(_c.c_double)]),
+    "crag_index_profile_read_ex": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double),
+                                              _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "crag_index_last_scan_kernel": (_c.c_char_p, [_P]),
     "crag_index_prefilter_row_bytes": (_c.c_int64, [_P]),
     "crag_index_prefilter_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64),

@@ -73,7 +73,7 @@ struct DevBuf {  // grow-only device scratch
 };
 
 struct EvSet {  // around one profiled search: start, before / after the scan kernel, end
-    hipEvent_t e0, e1, e2, e3;
+    hipEvent_t e0, e1a, e1, e2, e3;  // e1a, e1: recorded back to back (what an event pair measures with nothing between)
 };
 
 }  // namespace
@@ -99,12 +99,15 @@ struct crag_index {
         // prepared queries (fragment order) and the prefilter path's per-query state
         DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags;
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
+        bool done_recorded = false;  // ... once a second stream has appeared (single-stream callers pay no event)
         uint64_t last_use = 0;
     } ws[MAX_WS];
     uint64_t use_clock = 0;
+    bool multi_stream = false;  // more than one stream has searched this index
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
     bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false;
+    int env_pf_ablate = 0;
     int env_pf_nt = -1;                       // CRAG_PF_NT=0/1 forces the cache policy of the prefilter scan (developer switch)
     int64_t nt_above_bytes = 1536ll << 20;     // mirror bytes above which its loads stream (measured: no gain below ~1 GB)
     // a stored row whose norm lies outside [1e-30, 1e30]: the fp16 prefilter's error bound assumes normalised
@@ -166,6 +169,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     if (!ws)
         for (auto &w : ix->ws)
             if (!w.in_use) {
+                // a second stream: from now on every search records its workspace's completion event
+                if (&w != &ix->ws[0]) ix->multi_stream = true;
                 w.in_use = true;
                 w.stream = st;
                 ws = &w;
@@ -176,7 +181,12 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         // stream wait for the last search that used it (its owner may even be gone by now)
         for (auto &w : ix->ws)
             if (!ws || w.last_use < ws->last_use) ws = &w;
-        HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
+        if (ws->done_recorded) {
+            HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
+        } else {
+            // its last search predates the second stream (no event was recorded then): wait for the device
+            HIP_TRY(hipDeviceSynchronize());
+        }
         ws->stream = st;
     }
     ws->last_use = ++ix->use_clock;
@@ -193,9 +203,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     const int cap = 8192;  // candidates per query; a fuller list sets the overflow flag -> gated fp32 scan
     if (prefilter) {
         if ((rc = ws->a16.ensure((size_t)nq_pad * crag::DIM * 2))) return rc;
-        {   // the queries' bound records (zeroed by the prep kernel on every search) + one idle record of zeros
-            // per workgroup that nothing ever writes (zeroed once, when the buffer is allocated)
-            const size_t need = (size_t)(nq_pad + G) * crag::PF_BOUND_CELLS * sizeof(uint32_t);
+        {   // n_cu idle records of zeros that nothing ever writes (zeroed once, when the buffer is allocated; at the
+            // FRONT, so that no later search with fewer queries finds an old query record there), then the queries'
+            // bound records (zeroed by the prep kernel on every search)
+            const size_t need = (size_t)(ix->n_cu + nq_pad) * crag::PF_BOUND_CELLS * sizeof(uint32_t);
             if (need > ws->pf_gbound.bytes) {
                 if ((rc = ws->pf_gbound.ensure(need))) return rc;
                 HIP_TRY(hipMemsetAsync(ws->pf_gbound.p, 0, ws->pf_gbound.bytes, st));
@@ -217,6 +228,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         if (ix->ev_used == ix->ev_pool.size()) {
             EvSet t;
             HIP_TRY(hipEventCreate(&t.e0));
+            HIP_TRY(hipEventCreate(&t.e1a));
             HIP_TRY(hipEventCreate(&t.e1));
             HIP_TRY(hipEventCreate(&t.e2));
             HIP_TRY(hipEventCreate(&t.e3));
@@ -234,7 +246,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     pp.qinv = (float *)ws->qinv.p;
     pp.a32 = (float *)ws->a32.p;
     pp.a16 = prefilter ? (_Float16 *)ws->a16.p : nullptr;
-    pp.pf_gbound = prefilter ? (uint32_t *)ws->pf_gbound.p : nullptr;
+    pp.pf_gbound = prefilter ? (uint32_t *)ws->pf_gbound.p + (size_t)ix->n_cu * crag::PF_BOUND_CELLS : nullptr;
     pp.pf_count = prefilter ? (uint32_t *)ws->pf_count.p : nullptr;
     pp.pf_flags = prefilter ? (uint32_t *)ws->pf_flags.p : nullptr;
     HIP_TRY(crag::launch_prep_queries(pp, nq_pad, st));
@@ -275,7 +287,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     mp.k = k;
     mp.G = G;
 
-    if (ev) HIP_TRY(hipEventRecord(ev->e1, st));
+    if (ev) {
+        HIP_TRY(hipEventRecord(ev->e1a, st));
+        HIP_TRY(hipEventRecord(ev->e1, st));
+    }
     if (prefilter) {
         // K1: fp16 scan -> candidates;  K2: the fp32 scan, which exits at once unless a candidate list
         // overflowed;  K3: exact rescoring + selection (or the merge of K2's lists)
@@ -287,7 +302,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.qinv = (const float *)ws->qinv.p;
         fp.mask = (const uint32_t *)d_mask;
         fp.mask_stride_w = mask_stride / 4;
-        fp.gbound = (uint32_t *)ws->pf_gbound.p;
+        fp.gbound_idle = (const uint32_t *)ws->pf_gbound.p;
+        fp.gbound = (uint32_t *)ws->pf_gbound.p + (size_t)ix->n_cu * crag::PF_BOUND_CELLS;
         fp.cand = (uint2 *)ws->pf_cand.p;
         fp.count = (uint32_t *)ws->pf_count.p;
         fp.flags = (uint32_t *)ws->pf_flags.p;
@@ -298,6 +314,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.reverse = sp.reverse;
         fp.sets = k <= 24 ? 1 : (k <= 48 ? 2 : 4);
         fp.cap = cap;
+        fp.ablate = ix->env_pf_ablate;
         {   // streaming cache policy for a mirror far larger than the Infinity Cache (see prefilter_kernel)
             const int64_t streamed = ix->size * (int64_t)crag::DIM * 2;
             fp.nt = !ix->corpus16 ? 0 : (ix->env_pf_nt >= 0 ? ix->env_pf_nt : (streamed > ix->nt_above_bytes ? 1 : 0));
@@ -329,7 +346,11 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         HIP_TRY(crag::launch_merge_partials(mp, nq, st));
     }
     if (ev) HIP_TRY(hipEventRecord(ev->e3, st));
-    HIP_TRY(hipEventRecord(ws->done, st));  // what a stream that later takes this workspace over waits for
+    // what a stream that later takes this workspace over waits for.  Recorded only once a second stream has used the
+    // index: a single-stream caller (the common case) pays no event packet per search, and a workspace can be taken
+    // over only when MAX_WS other streams exist.
+    ws->done_recorded = ix->multi_stream;
+    if (ix->multi_stream) HIP_TRY(hipEventRecord(ws->done, st));
     return CRAG_OK;
 }
 
@@ -421,6 +442,7 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
     if (const char *v = getenv("CRAG_PF_NT")) ix->env_pf_nt = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("CRAG_PF_ABLATE")) ix->env_pf_ablate = atoi(v);
     if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
         // + 2 KiB per row beside the 4 KiB fp32 row: the prefilter scan then streams half the bytes.  Padding rows
@@ -452,6 +474,7 @@ int crag_index_destroy(crag_index *ix) {
     (void)hipDeviceSynchronize();
     for (auto &t : ix->ev_pool) {
         (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1a);
         (void)hipEventDestroy(t.e1);
         (void)hipEventDestroy(t.e2);
         (void)hipEventDestroy(t.e3);
@@ -780,26 +803,34 @@ int crag_index_profile_enable(crag_index *ix, int enabled) {
     return CRAG_OK;
 }
 
-int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
-                            double *merge_ms_total) {
+int crag_index_profile_read_ex(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
+                               double *merge_ms_total, double *event_pair_ms_total) {
     if (!ix) return fail(CRAG_EINVAL, "index is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard guard(ix->device);
-    double scan = 0.0, merge = 0.0;
+    double scan = 0.0, merge = 0.0, pair = 0.0;
     for (size_t i = 0; i < ix->ev_used; ++i) {
-        float a = 0.f, b = 0.f, c = 0.f;
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
         HIP_TRY(hipEventSynchronize(ix->ev_pool[i].e3));
-        HIP_TRY(hipEventElapsedTime(&a, ix->ev_pool[i].e0, ix->ev_pool[i].e1));
+        HIP_TRY(hipEventElapsedTime(&a, ix->ev_pool[i].e0, ix->ev_pool[i].e1a));
+        HIP_TRY(hipEventElapsedTime(&d, ix->ev_pool[i].e1a, ix->ev_pool[i].e1));
         HIP_TRY(hipEventElapsedTime(&b, ix->ev_pool[i].e1, ix->ev_pool[i].e2));
         HIP_TRY(hipEventElapsedTime(&c, ix->ev_pool[i].e2, ix->ev_pool[i].e3));
         scan += b;
         merge += a + c;
+        pair += d;
     }
     if (n_launches) *n_launches = (int64_t)ix->ev_used;
     if (scan_ms_total) *scan_ms_total = scan;
     if (merge_ms_total) *merge_ms_total = merge;
+    if (event_pair_ms_total) *event_pair_ms_total = pair;
     ix->ev_used = 0;
     return CRAG_OK;
+}
+
+int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
+                            double *merge_ms_total) {
+    return crag_index_profile_read_ex(ix, n_launches, scan_ms_total, merge_ms_total, nullptr);
 }
 
 int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candidates, int64_t *rescored_rows) {

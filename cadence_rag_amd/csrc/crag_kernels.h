@@ -76,6 +76,7 @@ struct PfParams {
     const uint32_t *mask;
     int64_t mask_stride_w;
     uint32_t *gbound;         // [nq_pad][PF_BOUND_CELLS] class maxima (orderable scores, atomic max)
+    const uint32_t *gbound_idle;  // [>= G][PF_BOUND_CELLS] zeros that nothing writes: where the loads of dead queries go
     uint2 *cand;              // [nq_pad][cap]: x = orderable approximate score, y = row position
     uint32_t *count;          // [nq_pad]
     uint32_t *flags;
@@ -84,6 +85,7 @@ struct PfParams {
     int sets;                 // 1, 2 or 4 class sets (<= k)
     int nt;                   // corpus loads with the streaming cache policy (corpus larger than the Infinity Cache)
     int cap;
+    int ablate;               // developer switch (CRAG_PF_ABLATE): parts of the kernel switched off for timing, results invalid
 };
 
 struct FinParams {

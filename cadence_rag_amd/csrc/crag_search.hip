@@ -1671,17 +1671,19 @@ __device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, c
     }
 }
 
-// staged candidates -> the per-query global lists (all threads of the workgroup; contains barriers)
-template <int NQB>
+// staged candidates -> the per-query global lists (all threads of the workgroup; contains barriers).  LAST: the
+// workgroup ends behind this flush, nothing is reset.
+template <int NQB, bool LAST = false>
 __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64_t window_row0) {
     __syncthreads();
     const uint32_t n = L.n_stage < (uint32_t)PF_STAGE ? L.n_stage : (uint32_t)PF_STAGE;
     const int tid = threadIdx.x;
+    if (LAST && (n == 0u || (p.ablate & 1))) return;  // (uniform)
     if (tid < 32 * NQB) {
         const uint32_t cnt = L.qcount[tid];
         const int qg = (int)blockIdx.y * (32 * NQB) + tid;
         L.qbase[tid] = cnt ? atomicAdd(&p.count[qg], cnt) : 0u;
-        L.qcount[tid] = 0u;
+        if (!LAST) L.qcount[tid] = 0u;
         L.qfill[tid] = 0u;
     }
     __syncthreads();
@@ -1696,6 +1698,7 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
             p.flags[0] = 1u;  // this query's list is full: the exact scan behind us takes over
         }
     }
+    if (LAST) return;
     __syncthreads();
     if (tid == 0) L.n_stage = 0u;
     __syncthreads();
@@ -1728,29 +1731,29 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // half cached (83 vs 71 us at 100 000 rows, 705 vs 660 us at 1M).
     constexpr int AUX = NT ? 2 : 0;
     __shared__ PfLds<NQB> L;
-    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
-    {   // whole tiles per workgroup
-        const int64_t nt = (p.n_rows + 31) >> 5;
-        c.t_begin = (nt * c.g) / p.G;
-        const int64_t t_end = (nt * (c.g + 1)) / p.G;
-        c.n_tiles = (int)(t_end - c.t_begin);
-        c.r_begin = c.t_begin * 32;
-        c.r_end = t_end * 32 < p.n_rows ? t_end * 32 : p.n_rows;
+    // Prologue order matters (a scan of 100 000 rows is only ~13 tiles per workgroup): the first tile's corpus loads
+    // and the query fragments leave before anything waits on memory; the owned queries' norms (one vector load)
+    // ride behind them.  [Before: four dependent qinv loads, each waited for, and two 64-bit divisions stood in
+    // front of the first corpus load.]
+    ScanCtx c;
+    c.lane = threadIdx.x & 63;
+    c.w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    c.g = blockIdx.x;
+    c.qb = blockIdx.y;
+    c.j = c.lane & 31;
+    c.h = c.lane >> 5;
+    c.reverse = p.reverse != 0;
+    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * (16 << PIECE_SHIFT) + c.h * 16);
+    {   // whole tiles per workgroup: tiles [nt*g/G, nt*(g+1)/G) in 32-bit arithmetic (nt < 2^27, G < 2^16)
+        const uint32_t nt = (uint32_t)((p.n_rows + 31) >> 5), G = (uint32_t)p.G, g = (uint32_t)c.g;
+        const uint32_t qt = nt / G, rt = nt - qt * G;
+        const uint32_t t0 = qt * g + (rt * g) / G, t1 = qt * (g + 1) + (rt * (g + 1)) / G;
+        c.t_begin = t0;
+        c.n_tiles = (int)(t1 - t0);
+        c.r_begin = (int64_t)t0 * 32;
+        c.r_end = (int64_t)t1 * 32 < p.n_rows ? (int64_t)t1 * 32 : p.n_rows;
     }
     const int lane = c.lane, w = c.w, j = c.j, h = c.h;
-
-    PfOwner<NQB> o;
-    {
-        const int R = w * RPO, qb = R >> 4, r = R & 15;
-        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
-        o.okmask = 0u;
-#pragma unroll
-        for (int e = 0; e < RPO; ++e)
-            if (o.qg0 + e < p.nq && p.qinv[o.qg0 + e] > 0.f) o.okmask |= 1u << e;
-    }
-    if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) L.n_stage = 0u;
 
     // B operand source.  fp32 rows (tile32 layout): two 16-byte loads per k-step, normalised and rounded to fp16
     // in registers.  fp16 mirror (store_rows_kernel): one 16-byte load per k-step, already the MFMA operand --
@@ -1778,13 +1781,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
     // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
     f16x8 a[NQB][8];
+    if (!(p.ablate & 16)) {
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        const f16x8 *af = reinterpret_cast<const f16x8 *>(p.a16) +
-                          ((size_t)(((int)blockIdx.y * NQB + qb) * SCAN_WAVES + w) * 8) * 64 + lane;
+        for (int qb = 0; qb < NQB; ++qb) {
+            const f16x8 *af = reinterpret_cast<const f16x8 *>(p.a16) +
+                              ((size_t)(((int)blockIdx.y * NQB + qb) * SCAN_WAVES + w) * 8) * 64 + lane;
 #pragma unroll
-        for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
+            for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
+        }
+    } else {
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
+
+    PfOwner<NQB> o;
+    {
+        const int R = w * RPO, qb = R >> 4, r = R & 15;
+        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
+        // the RPO owned queries are consecutive and qg0 is a multiple of RPO: one aligned vector load (qinv is
+        // nq_pad long; padded queries hold 0)
+        typedef float qv_t __attribute__((ext_vector_type(RPO)));
+        const qv_t qi = *reinterpret_cast<const qv_t *>(p.qinv + o.qg0);
+        o.okmask = 0u;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            if (o.qg0 + e < p.nq && qi[e] > 0.f) o.okmask |= 1u << e;
+    }
+    if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) L.n_stage = 0u;
     // the first two tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
     float stash[RPO], stash2[RPO];
 #pragma unroll
@@ -1813,7 +1840,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     uint32_t *const gb_row = p.gbound + (size_t)o.qg0 * PF_BOUND_CELLS + j;  // class j of the first owned query
     // a record of zeros nobody writes, one per workgroup: where the loads of a padded / zero query go (no branch
     // per query around the loads)
-    const uint32_t *const idle_row = p.gbound + ((size_t)gridDim.y * (32 * NQB) + c.g) * PF_BOUND_CELLS + j;
+    const uint32_t *const idle_row = p.gbound_idle + (size_t)c.g * PF_BOUND_CELLS + j;
 
     auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
 #pragma unroll
@@ -1853,7 +1880,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         const uint32_t vnext = voff(ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
-        const bool rd = ti == next_read;  // uniform
+        const bool rd = ti == next_read && !(p.ablate & 4);  // uniform
         // operands of this tile's epilogue, behind the B loads of this tile (in flight) and in front of the next one's
         float inv_nxt = 1.f;
         if constexpr (!MIRROR) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1 < c.n_tiles ? ti + 1 : ti)) * 32 + j];
@@ -1950,7 +1977,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                     lmax[e][s] = ord;
                     dirty |= 1u << (e * SETS + s);
                 }
-            pass[e] = sc[e] >= thr[e];
+            pass[e] = sc[e] >= thr[e] && !(p.ablate & 8);
         }
         if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
 #pragma unroll
@@ -1982,7 +2009,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                             lift = lift && (v >= (uint32_t)__shfl((int)sorted, (lane & 32) | (SETS - 1)));
                         }
                     }
-                    if (lift)
+                    if (lift && !(p.ablate & 2))
                         (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + s * 32, v, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1993,7 +2020,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         inv_cur = inv_nxt;
     }
     if (c.n_tiles > 0) {  // the first two tiles, against the bounds the wave holds now
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        // flush first if the staging buffer is nearly full: decided as in the loop, behind ONE barrier (each wave
+        // posts what it saw after its own last append)
+        auto flush_if_full = [&]() {
+            if (lane == 0) L.want_flush[buf][w] = L.n_stage > (uint32_t)PF_FLUSH_ABOVE ? 1u : 0u;
+            __syncthreads();
+            const u32x4 f0 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][0]);
+            const u32x4 f1 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][4]);
+            buf ^= 1;
+            if ((f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0u) pf_flush<NQB>(p, L, c.t_begin * 32);
+        };
+        flush_if_full();
         // (a last read of the shared maxima would pass ~4 rows per query fewer of these 64 rows x 256 workgroups
         // and cost every workgroup a device-coherent load + sort at its very end: only a wave without any bound
         // asks)
@@ -2007,14 +2044,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         }
         bool pass[RPO];
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
+        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e] && !(p.ablate & 8);
         pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
-        if (__syncthreads_or(L.n_stage > (uint32_t)PF_FLUSH_ABOVE)) pf_flush<NQB>(p, L, c.t_begin * 32);
+        flush_if_full();
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e];
+        for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e] && !(p.ablate & 8);
         pf_stage<NQB>(L, o, stash2, pass, stash2_row, p.flags);
     }
-    pf_flush<NQB>(p, L, c.t_begin * 32);
+    pf_flush<NQB, true>(p, L, c.t_begin * 32);
 }
 
 // ---- K3: candidates -> exact top-k.  One 256-thread workgroup per query ---------------------------------------

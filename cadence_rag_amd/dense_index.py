@@ -197,6 +197,14 @@ class DenseIndex:
                                                         ctypes.byref(merge)), "profile_read")
         return int(n.value), float(scan.value), float(merge.value)
 
+    def profile_read_ex(self) -> Tuple[int, float, float, float]:
+        """(samples, scan ms total, rest ms total, back-to-back event pair ms total): see crag_index_profile_read_ex."""
+        n = ctypes.c_int64(0)
+        scan, merge, pair = ctypes.c_double(0.0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+        _native.check(self._lib.crag_index_profile_read_ex(self._h, ctypes.byref(n), ctypes.byref(scan),
+                                                           ctypes.byref(merge), ctypes.byref(pair)), "profile_read_ex")
+        return int(n.value), float(scan.value), float(merge.value), float(pair.value)
+
     def prefilter_stats(self) -> dict:
         """Searches / candidates / exactly rescored rows of the prefilter path since the last call."""
         a, b, c = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)

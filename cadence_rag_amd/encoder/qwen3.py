@@ -186,8 +186,14 @@ class Qwen3Encoder:
         return enc
 
     @classmethod
-    def from_pretrained(cls, path: str, device: Optional[torch.device] = None) -> "Qwen3Encoder":
-        """Local directory with config.json, *.safetensors and tokenizer files (nothing is fetched)."""
+    def from_pretrained(cls, path: str, device: Optional[torch.device] = None, *, out_dim: Optional[int] = None,
+                        max_length: int = 1024, pooling: str = "last", model_id: Optional[str] = None
+                        ) -> "Qwen3Encoder":
+        """Local directory with config.json, *.safetensors and tokenizer files (nothing is fetched): the gateway's
+        startup (RUNBOOK:657-660: AutoTokenizer.from_pretrained(TOKENIZER_PATH, local_files_only=True)) plus the
+        checkpoint the ONNX export was made from.  Tensor names are transformers' (`layers.N...` of Qwen3Model, or
+        `model.layers.N...` of a *ForCausalLM checkpoint; `lm_head.*` is ignored).  out_dim: EMBED_OUTPUT_DIM
+        (default min(1024, hidden)); max_length: EMBED_MAX_LENGTH (RUNBOOK:484)."""
         import json
         from pathlib import Path
 
@@ -198,9 +204,16 @@ class Qwen3Encoder:
         cfg = Qwen3Config(hidden_size=hf["hidden_size"], num_layers=hf["num_hidden_layers"],
                           num_heads=hf["num_attention_heads"], num_kv_heads=hf["num_key_value_heads"],
                           head_dim=hf.get("head_dim", 128), intermediate_size=hf["intermediate_size"],
-                          vocab_size=hf["vocab_size"], rms_norm_eps=hf.get("rms_norm_eps", 1e-6), rope_theta=rope)
+                          vocab_size=hf["vocab_size"], rms_norm_eps=hf.get("rms_norm_eps", 1e-6), rope_theta=rope,
+                          max_length=int(max_length), out_dim=int(out_dim or min(1024, hf["hidden_size"])),
+                          pooling=pooling, model_id=model_id or hf.get("_name_or_path") or str(root.name))
+        if cfg.out_dim > cfg.hidden_size:
+            raise ValueError(f"out_dim {cfg.out_dim} exceeds the model's hidden size {cfg.hidden_size}")
+        files = sorted(root.glob("*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {root}")
         sd: Dict[str, torch.Tensor] = {}
-        for f in sorted(root.glob("*.safetensors")):
+        for f in files:
             sd.update(load_file(str(f)))
         prefix = "model." if any(k.startswith("model.") for k in sd) else ""
         enc = cls.from_state_dict(cfg, sd, device, prefix=prefix)
@@ -286,12 +299,16 @@ class Qwen3Encoder:
         return self.forward_packed(ids, batch)
 
     # -- the Encoder protocol of cadence_rag_amd.embeddings ------------------------------------------
-    def encode_device(self, texts: Sequence[str]) -> Tuple[torch.Tensor, str]:
-        """texts -> unit-norm embeddings [n, out_dim] fp32 ON THE DEVICE (embeddings.embed_texts_device)."""
+    def tokenize(self, texts: Sequence[str]) -> List[List[int]]:
+        """The gateway's tokenizer call (RUNBOOK:689-699: truncation=True, max_length=EMBED_MAX_LENGTH) without its
+        padding: sequences are packed, not padded."""
         if self.tokenizer is None:
             raise RuntimeError("no tokenizer loaded (Qwen3Encoder.from_pretrained, or set .tokenizer)")
-        enc = self.tokenizer(list(texts), truncation=True, max_length=self.cfg.max_length, padding=False)["input_ids"]
-        return self.embed_token_lists(enc), self.cfg.model_id
+        return self.tokenizer(list(texts), truncation=True, max_length=self.cfg.max_length, padding=False)["input_ids"]
+
+    def encode_device(self, texts: Sequence[str]) -> Tuple[torch.Tensor, str]:
+        """texts -> unit-norm embeddings [n, out_dim] fp32 ON THE DEVICE (embeddings.embed_texts_device)."""
+        return self.embed_token_lists(self.tokenize(texts)), self.cfg.model_id
 
     def encode(self, texts: Sequence[str]) -> Tuple[List[List[float]], str]:
         vecs, model = self.encode_device(texts)

@@ -117,17 +117,23 @@ class TechTokenIndex:
                                              out_ct.data_ptr(), ctypes.c_void_p(stream)), "crag_tech_lane")
         return out_ids, out_ct
 
-    def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0):
-        """query_token_lists: per query the tokens of extract_tech_tokens(query) (at most 64 queries), any
+    def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0,
+               verify: "bool | None" = None):
+        """verify (default: whatever the index was built with): check the returned rows' token STRINGS on the host.
+        That check copies ids and counts to the host and therefore SYNCHRONISES the caller's stream; pass
+        verify=False on a batched, stream-ordered path (HybridSearcher does) — the lane then differs from the SQL
+        `&&` only by a 64-bit hash collision (2^-64 per comparison).
+        query_token_lists: per query the tokens of extract_tech_tokens(query) (at most 64 queries), any
         number of tokens per query: the SQL `tech_tokens && :tokens` has no bound either.  The kernel takes 32
         tokens per query and launch; a longer list (a pasted log with many URLs / hashes) runs in several
         passes whose hits are merged in the lane's static order.
         Returns (ids int64 [nq, k] -1 padded, counts int32 [nq]) CUDA tensors, best (most recent) first."""
         lists = [list(dict.fromkeys(toks)) for toks in query_token_lists]  # distinct, first occurrence kept
+        check = (self._row_tokens is not None) if verify is None else (bool(verify) and self._row_tokens is not None)
         passes = max(1, max((-(-len(t) // MAX_QUERY_TOKENS) for t in lists), default=1))
         if passes == 1:
             out_ids, out_ct = self._pass(lists, k, row_mask, mask_stride, stream)
-            if self._row_tokens is not None:
+            if check:
                 out_ids, out_ct = self._verified(lists, k, out_ids, out_ct, row_mask, mask_stride, stream)
             return out_ids, out_ct
         if self._rank_of_id is None:
@@ -150,7 +156,7 @@ class TechTokenIndex:
             out_ct[q] = len(best)
         with _on_stream(stream, self.device):
             d_ids, d_ct = torch.from_numpy(out_ids).to(self.device), torch.from_numpy(out_ct).to(self.device)
-        if self._row_tokens is not None:
+        if check:
             d_ids, d_ct = self._verified(lists, k, d_ids, d_ct, row_mask, mask_stride, stream)
         return d_ids, d_ct
 
@@ -198,8 +204,11 @@ class HybridSearcher:
     lane order bm25 -> tech_tokens -> dense."""
 
     def __init__(self, index, tech_index: "TechTokenIndex | None" = None, *, dense_k: int = 50, tech_k: int = 50,
-                 rrf_k: int = DEFAULT_RRF_K) -> None:
+                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False) -> None:
+        """verify_tokens: run the exact-token lane's host-side string check (a blocking D2H copy per step); off by
+        default so that a step only enqueues work on the caller's stream."""
         self.index, self.tech = index, tech_index
+        self.verify_tokens = bool(verify_tokens)
         self.dense_k, self.tech_k, self.rrf_k = int(dense_k), int(tech_k), int(rrf_k)
         self._dense_out: dict = {}  # per (stream, batch size): results of calls on different streams stay apart
 
@@ -208,7 +217,8 @@ class HybridSearcher:
         """query_vectors [nq, dim] fp32 CUDA; query_token_lists: per query its extract_tech_tokens();
         bm25: (ids int64 [nq, w] CUDA, counts int32 [nq] CUDA) or None; row_mask: packed bits per row
         position (uint8 CUDA), shared (mask_stride 0) or per query.  Returns rrf_fuse's dict plus the dense
-        lane itself ("dense_ids", "dense_scores", "dense_counts").  Everything is enqueued on `stream`; the
+        lane itself ("dense_ids", "dense_scores", "dense_counts").  Everything is enqueued on `stream` (token
+        lists longer than 32 tokens and verify_tokens=True are the exceptions: both visit the host); the
         dense buffers are reused by the next call with the same stream and batch size (the returned tensors
         are valid until then), and the caller orders `query_vectors` / `row_mask` / `bm25` with `stream`."""
         nq = int(query_vectors.shape[0])
@@ -226,7 +236,7 @@ class HybridSearcher:
             lanes.append(bm25)
         if self.tech is not None and query_token_lists is not None:
             lanes.append(self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
-                                          stream=stream))
+                                          stream=stream, verify=self.verify_tokens))
         lanes.append((d_ids, d_ct))
         width = sum(int(t.shape[1]) for t, _ in lanes)
         out = rrf_fuse(lanes, out_k=out_k or width, rrf_k=self.rrf_k, stream=stream)

@@ -121,6 +121,12 @@ class DenseTable:
         self.call_started_at = np.empty((0,), dtype="datetime64[us]")
         self.call_ids = np.empty((0,), dtype=object)
         self.call_tags: Dict[Any, Sequence[str]] = {}
+        # bumped whenever rows are appended or move: whatever is built over row POSITIONS (the exact-token lane,
+        # packed masks) is stale once it differs
+        self.generation = 0
+        # per-row tech_tokens (the `tech_tokens text[]` column), kept once a tech lane was built so that the lane
+        # can be rebuilt when the table changes; None = not tracked
+        self.tech_tokens: Optional[List[List[str]]] = None
 
     def __len__(self) -> int:
         return len(self.index)
@@ -128,12 +134,24 @@ class DenseTable:
     def close(self) -> None:
         self.index.close()
 
+    def _take_tokens(self, columns: Dict[str, Sequence[Any]], n: int) -> Tuple[Dict[str, Sequence[Any]], List[List[str]]]:
+        """Split an optional "tech_tokens" entry off the SELECTed columns (it feeds the exact-token lane, it is not
+        a response column)."""
+        if "tech_tokens" not in columns:
+            return columns, [[] for _ in range(n)]
+        columns = dict(columns)
+        toks = [list(t or []) for t in columns.pop("tech_tokens")]
+        if len(toks) != n:
+            raise ValueError("tech_tokens must have one entry per vector")
+        return columns, toks
+
     def add(self, vectors, columns: Dict[str, Sequence[Any]], call_started_at: Optional[Sequence[Any]] = None,
             call_tags: Optional[Dict[Any, Sequence[str]]] = None) -> None:
         """Append rows whose ids are ascending and above every stored id (the C ABI's contract); the
         index grows when its capacity is exhausted.  Rows that may arrive out of id order go through
-        `insert`."""
+        `insert`.  `columns` may carry "tech_tokens" (per-row token lists) for the exact-token lane."""
         n = len(columns[self.id_field])
+        columns, toks = self._take_tokens(columns, n)
         if any(len(v) != n for v in columns.values()):
             raise ValueError("all columns must have one entry per vector")
         ids = np.asarray(columns[self.id_field], dtype=np.int64)
@@ -147,7 +165,10 @@ class DenseTable:
         self.call_started_at = np.concatenate([self.call_started_at, ts])
         if call_tags:
             self.call_tags.update(call_tags)
+        if self.tech_tokens is not None:
+            self.tech_tokens.extend(toks)
         self._pos_of_id = None
+        self.generation += 1
 
     def _reserve(self, n_more: int) -> None:
         """Make room for n_more rows: the HBM index has a fixed capacity, so a full one is replaced by a
@@ -176,7 +197,7 @@ class DenseTable:
                 rows = torch.empty(n_old, old.dim, dtype=torch.float32, device=dev)
                 ids = old.get_rows_into(0, n_old, rows) if n_old else np.empty((0,), dtype=np.int64)
                 if extra is not None:
-                    rows = torch.cat([rows, torch.as_tensor(np.asarray(extra[0], dtype=np.float32), device=dev)])
+                    rows = torch.cat([rows, _rows_on_device(extra[0], len(extra[1]), old.dim, dev)])
                     ids = np.concatenate([ids, np.asarray(extra[1], dtype=np.int64)])
                 if order is not None:
                     rows = rows[torch.as_tensor(order, device=dev)]
@@ -187,6 +208,7 @@ class DenseTable:
             raise
         self.index = new
         old.close()
+        self.generation += 1
 
     def insert(self, vectors, columns: Dict[str, Sequence[Any]], call_started_at: Optional[Sequence[Any]] = None,
                call_tags: Optional[Dict[Any, Sequence[str]]] = None) -> None:
@@ -201,14 +223,15 @@ class DenseTable:
         old_ids = np.asarray(self.columns.get(self.id_field, []), dtype=np.int64)
         if (old_ids.size == 0 or new_ids.min() > old_ids[-1]) and np.all(np.diff(new_ids) > 0):
             return self.add(vectors, columns, call_started_at, call_tags)
+        columns, toks = self._take_tokens(columns, n)
         if any(len(v) != n for v in columns.values()):
             raise ValueError("all columns must have one entry per vector")
         all_ids = np.concatenate([old_ids, new_ids])
         order = np.argsort(all_ids, kind="stable")
         if np.any(np.diff(all_ids[order]) == 0):
             raise ValueError(f"duplicate {self.id_field} in insert")
-        vec = np.asarray(vectors, dtype=np.float32).reshape(n, -1)
-        self._rebuild(capacity=max(self.index.capacity, all_ids.size), order=order, extra=(vec, new_ids))
+        # `vectors` may be a CUDA tensor (the device-resident backfill): it stays on the device
+        self._rebuild(capacity=max(self.index.capacity, all_ids.size), order=order, extra=(vectors, new_ids))
         for key in set(self.columns) | set(columns):
             merged = list(self.columns.get(key, [None] * old_ids.size)) + list(columns.get(key, [None] * n))
             self.columns[key] = [merged[i] for i in order]
@@ -218,13 +241,18 @@ class DenseTable:
         self.call_ids = np.concatenate([self.call_ids, np.asarray(list(columns["call_id"]), dtype=object)])[order]
         if call_tags:
             self.call_tags.update(call_tags)
+        if self.tech_tokens is not None:
+            merged_t = self.tech_tokens + toks
+            self.tech_tokens = [merged_t[i] for i in order]
         self._pos_of_id = None
+        self.generation += 1
 
     def sink(self, row_columns):
         """Backfill sink (embedding_pipeline.BackfillStore.update_embeddings -> HBM): an object whose
         `add(vectors, ids=...)` asks `row_columns(ids)` for the rows' SELECTed columns — a dict of column
-        lists that may also carry "call_started_at" — and inserts them here, so that the host-side columns,
-        the filter masks and the index stay one table."""
+        lists that may also carry "call_started_at" and "tech_tokens" — and inserts them here, so that the
+        host-side columns, the filter masks, the exact-token lane and the index stay one table.  `vectors` may be
+        host lists / arrays or a CUDA tensor (DeviceSinkStore)."""
         table = self
 
         class _Sink:
@@ -328,21 +356,39 @@ class DenseTable:
                       call_tags=call_tags if lo == 0 else None)
         return table, tokens
 
-    def build_tech_lane(self, row_tokens: Sequence[Sequence[str]]):
+    def build_tech_lane(self, row_tokens: Optional[Sequence[Sequence[str]]] = None):
         """GPU exact-token lane over this table's rows (row i <-> position i, so filter masks are shared):
-        the `tech_tokens text[]` column + ORDER BY call_started_at DESC, id ASC (retrieve.py:183-242)."""
+        the `tech_tokens text[]` column + ORDER BY call_started_at DESC, id ASC (retrieve.py:183-242).
+        The table keeps the tokens from here on (rows added later bring theirs in `columns["tech_tokens"]`), and
+        the lane remembers the table generation it was built for: GpuRetrieveBackend rebuilds a stale lane."""
         import torch
 
         from .fusion import TechTokenIndex
+        if row_tokens is None:
+            row_tokens = self.tech_tokens
+            if row_tokens is None:
+                raise ValueError("this table does not track tech_tokens yet: pass row_tokens")
         if len(row_tokens) != len(self):
             raise ValueError("row_tokens must have one entry per table row")
-        return TechTokenIndex(row_tokens, np.asarray(self.columns[self.id_field], dtype=np.int64),
+        self.tech_tokens = [list(t or []) for t in row_tokens]
+        lane = TechTokenIndex(self.tech_tokens, np.asarray(self.columns[self.id_field], dtype=np.int64),
                               self.call_started_at, torch.device("cuda", self.index.device))
+        lane.table_generation = self.generation
+        return lane
 
     def _positions(self) -> Dict[int, int]:
         if getattr(self, "_pos_of_id", None) is None:
             self._pos_of_id = {int(v): i for i, v in enumerate(self.columns[self.id_field])}
         return self._pos_of_id
+
+
+def _rows_on_device(vectors, n: int, dim: int, dev):
+    """[n, dim] float32 on `dev` from host lists / numpy or from a torch tensor (a CUDA tensor never visits the
+    host)."""
+    import torch
+    if isinstance(vectors, torch.Tensor):
+        return vectors.to(device=dev, dtype=torch.float32).reshape(n, dim)
+    return torch.as_tensor(np.asarray(vectors, dtype=np.float32).reshape(n, dim), device=dev)
 
 
 def _native_max_k() -> int:
@@ -472,6 +518,13 @@ class GpuRetrieveBackend(RetrieveBackend):
         if not tokens or lane is None or len(table) == 0:
             return []
         import torch
+        if getattr(lane, "table_generation", table.generation) != table.generation or lane.n != len(table):
+            # rows were appended or moved since the lane was built: its row positions (and with them every packed
+            # mask bit) no longer mean the table's rows
+            if table.tech_tokens is None or len(table.tech_tokens) != len(table):
+                raise RuntimeError(f"the exact-token lane of {name} is stale (table generation {table.generation}) "
+                                   "and the table does not track tech_tokens: rebuild it with build_tech_lane")
+            lane = self._tech[name] = table.build_tech_lane()
         mask = table.filter_mask(filters, call_ids)
         d_mask = None
         if mask is not None:

@@ -164,6 +164,11 @@ int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint6
 int crag_index_profile_enable(crag_index *ix, int enabled);
 int crag_index_profile_read(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
                             double *merge_ms_total);
+/* The same + event_pair_ms_total: every sample also records two events back to back in front of the scan launch;
+ * their elapsed time is what an event pair measures with NOTHING between (the part of scan_ms_total that is event
+ * processing, not kernel: rocprofv3's begin/end timestamps of the kernel do not contain it). */
+int crag_index_profile_read_ex(crag_index *ix, int64_t *n_launches, double *scan_ms_total,
+                               double *merge_ms_total, double *event_pair_ms_total);
 
 /* Byte accounting of the prefilter path (fp16 MFMA scan + exact fp32 rescoring of the candidates, the path
  * searches over corpora of >= 128 rows per workgroup take): sums since the last call, then cleared.

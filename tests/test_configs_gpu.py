@@ -95,6 +95,77 @@ def test_one_million_rows_exact_duplicates_order_by_id(million):
     assert ix.count_eligible() == 1_000_000 - 2
 
 
+def test_hybrid_retrieve_at_full_size_one_million_chunks_batch_64(million):
+    """BASELINE configs[4] at its full size: 1M chunks, batch 64, dense top-100 + exact-token lane top-50 + given
+    BM25 ranks -> RRF, all on the GPU (fusion.HybridSearcher).  Checked: the dense leg against a sampled fp64 oracle;
+    the token lane against a vectorised host evaluation of `tech_tokens && :tokens ORDER BY call_started_at DESC,
+    id ASC LIMIT 50` (retrieve.py:183-242) for every query; the fused order against the host mirror of _rrf_merge
+    (retrieve.py:245-260, itself pinned by goldens from the reference) fed with the GPU lanes, for every query; and
+    the size-independent properties of RRF (score = sum of 1/(60 + rank) over the lanes that hit, descending,
+    distinct ids, lane bits)."""
+    import torch
+    from cadence_rag_amd import retrieve as rt
+    from cadence_rag_amd.fusion import HybridSearcher, TechTokenIndex
+    ix, host, q_all, planted = million
+    n, nq = 1_000_000, 64
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    vocab = np.array([f"TOK-{i}" for i in range(3000)])
+    n_tok = rng.integers(0, 4, size=n)
+    tok_idx = rng.integers(0, 3000, size=int(n_tok.sum()))
+    row_of_tok = np.repeat(np.arange(n), n_tok)
+    flat = vocab[tok_idx].tolist()
+    row_tokens, o = [], 0
+    for c in n_tok.tolist():
+        row_tokens.append(flat[o:o + c])
+        o += c
+    started = np.datetime64("2025-01-01", "us") + rng.integers(0, 500, size=n).astype("timedelta64[D]")
+    tech = TechTokenIndex(row_tokens, np.arange(n), started, dev, verify=False)
+    q_tok_idx = [rng.choice(3000, size=int(rng.integers(0, 4)), replace=False) for _ in range(nq)]
+    qtoks = [vocab[t].tolist() for t in q_tok_idx]
+    bm25 = np.stack([rng.choice(n, size=50, replace=False) for _ in range(nq)])
+    bm25_ct = rng.integers(0, 51, size=nq).astype(np.int32)
+    q = q_all[:nq]
+    hs = HybridSearcher(ix, tech, dense_k=100, tech_k=50)
+    out = hs.search(torch.from_numpy(q).to(dev), qtoks, (torch.from_numpy(bm25).to(dev), torch.from_numpy(bm25_ct).to(dev)))
+    torch.cuda.synchronize()
+    ids, cts = out["ids"].cpu().numpy(), out["counts"].cpu().numpy()
+    scs, lanes = out["scores"].cpu().numpy(), out["lanes"].cpu().numpy()
+    d_ids, d_sc, d_ct = (out[k].cpu().numpy() for k in ("dense_ids", "dense_scores", "dense_counts"))
+    # dense leg: top-100 vs the sampled fp64 oracle
+    sample = [0, 31, 63]
+    want = _sampled_oracle(host, q, 100, sample)
+    assert_topk_matches(d_ids[sample], d_sc[sample], d_ct[sample], *want, tol=TOL)
+    # token lane, every query: rows holding any query token, most recent call first, then id
+    t_ids, t_ct = (t.cpu().numpy() for t in tech.search(qtoks, 50))
+    order_key = np.lexsort((np.arange(n), -started.astype(np.int64)))        # rank -> row
+    rank_of = np.empty(n, dtype=np.int64)
+    rank_of[order_key] = np.arange(n)
+    for qi in range(nq):
+        hit_rows = np.unique(row_of_tok[np.isin(tok_idx, q_tok_idx[qi])]) if len(q_tok_idx[qi]) else np.empty(0, np.int64)
+        want_rows = hit_rows[np.argsort(rank_of[hit_rows])][:50]
+        assert t_ct[qi] == len(want_rows)
+        assert t_ids[qi, :t_ct[qi]].tolist() == want_rows.tolist()
+    # fusion, every query: the GPU lanes through the host mirror of _rrf_merge
+    bits = {"bm25": 1, "tech_tokens": 2, "dense": 4}
+    for qi in range(nq):
+        lanes_in = {"bm25": [{"id": int(v)} for v in bm25[qi, :bm25_ct[qi]]],
+                    "tech_tokens": [{"id": int(v)} for v in t_ids[qi, :t_ct[qi]]],
+                    "dense": [{"id": int(v)} for v in d_ids[qi, :d_ct[qi]]]}
+        ref = rt._rrf_merge(lanes_in, "id")
+        c = int(cts[qi])
+        assert c == len(ref) and len(set(ids[qi, :c].tolist())) == c
+        assert ids[qi, :c].tolist() == [row["id"] for row, _, _ in ref]
+        assert np.array_equal(scs[qi, :c], np.array([sc for _, _, sc in ref]))
+        assert lanes[qi, :c].tolist() == [sum(bits[l] for l in ls) for _, ls, _ in ref]
+        assert np.all(np.diff(scs[qi, :c]) <= 0)
+        # a row that only the dense lane found at rank r scores exactly 1/(60 + r)
+        only_dense = [i for i in range(c) if lanes[qi, i] == 4]
+        for i in only_dense[:5]:
+            r = int(np.nonzero(d_ids[qi] == ids[qi, i])[0][0]) + 1
+            assert scs[qi, i] == 1.0 / (60 + r)
+
+
 # ------------------------------------------------------------------------------------------------------
 # boundary rules of include/crag_dense.h
 # ------------------------------------------------------------------------------------------------------
@@ -160,6 +231,63 @@ def test_dense_table_insert_out_of_order_rebuilds_in_id_order(gpu):
         assert_topk_matches(*got, *want, tol=TOL)
         with pytest.raises(ValueError, match="duplicate"):
             sink.add(vecs[:1].tolist(), ids=[1005])
+    finally:
+        table.close()
+
+
+def test_device_resident_late_rows_and_the_token_lane_follow_the_table(gpu):
+    """(1) a CUDA tensor of late-embedded rows (ids below the stored maximum) goes through
+    DenseTable.sink / insert without visiting the host (DeviceSinkStore hands exactly that); (2) the exact-token lane
+    is built over row POSITIONS: once rows were appended or moved it is stale, and GpuRetrieveBackend rebuilds it from
+    the tokens the table tracks, so filters and token hits keep meaning the table's rows."""
+    import torch
+    from datetime import datetime
+    from uuid import UUID
+    from cadence_rag_amd import retrieve as rt
+    rng = np.random.default_rng(12)
+    vecs = unit_rows(rng, 120)
+    dev = torch.device("cuda", 0)
+    table = rt.DenseTable("chunks", "chunk_id", dim=1024, capacity=64)
+    try:
+        def cols(ids):
+            ids = list(ids)
+            return {"chunk_id": ids, "call_id": [UUID(int=1 + (i % 2)) for i in ids], "speaker": ["S"] * len(ids),
+                    "start_ts_ms": [0] * len(ids), "end_ts_ms": [1] * len(ids), "text": [f"row {i}" for i in ids],
+                    "call_started_at": [datetime(2024, 1, 1 + (i % 20)) for i in ids],
+                    "tech_tokens": [["ECONNRESET"] if i % 10 == 0 else [f"TOK-{i}"] for i in ids]}
+        first = cols(range(1000, 1060))
+        started, toks = first.pop("call_started_at"), first.pop("tech_tokens")
+        table.add(vecs[:60], first, call_started_at=started)
+        lane = table.build_tech_lane(toks)
+        backend = rt.GpuRetrieveBackend(table, rt.DenseTable("artifact_chunks", "artifact_chunk_id", dim=1024, capacity=1),
+                                        tech_chunks=lane)
+        before = [r["chunk_id"] for r in backend.fetch_chunks_tech(["ECONNRESET"], None, None, 50)]
+        assert sorted(before) == [i for i in range(1000, 1060) if i % 10 == 0]
+        gen = table.generation
+        sink = table.sink(lambda ids: cols(ids))
+        sink.add(torch.from_numpy(vecs[60:100]).to(dev), ids=list(range(500, 540)))      # late rows, CUDA tensor
+        sink.add(torch.from_numpy(vecs[100:120]).to(dev), ids=list(range(1060, 1080)))   # plain append, CUDA tensor
+        assert table.generation > gen and len(table) == 120
+        assert table.columns["chunk_id"] == list(range(500, 540)) + list(range(1000, 1080))
+        stored, ids = table.index.get_rows(0, 120)
+        assert np.array_equal(stored, np.concatenate([vecs[60:100], vecs[:60], vecs[100:120]]))
+        assert ids.tolist() == table.columns["chunk_id"]
+        # the stale lane is rebuilt: new rows are found, the order is (call_started_at DESC, id ASC), and a call_id
+        # filter (packed by CURRENT positions) selects exactly that call's rows
+        hits = backend.fetch_chunks_tech(["ECONNRESET"], None, None, 50)
+        want = sorted((i for i in table.columns["chunk_id"] if i % 10 == 0),
+                      key=lambda i: (-(1 + i % 20), i))
+        assert [r["chunk_id"] for r in hits] == want
+        assert backend._tech["chunks"].table_generation == table.generation
+        f = rt.RetrieveFilters(call_ids=[UUID(int=1)])
+        scoped = backend.fetch_chunks_tech(["ECONNRESET", "TOK-501", "TOK-1077"], f, f.call_ids, 50)
+        assert scoped and all(r["call_id"] == UUID(int=1) for r in scoped)
+        assert {r["chunk_id"] for r in scoped} == {i for i in want if i % 2 == 0}
+        # a table that does not track tokens refuses to answer from a stale lane
+        table.tech_tokens = None
+        table.add(vecs[:1], {k: v for k, v in cols([2000]).items() if k not in ("call_started_at", "tech_tokens")})
+        with pytest.raises(RuntimeError, match="stale"):
+            backend.fetch_chunks_tech(["ECONNRESET"], None, None, 5)
     finally:
         table.close()
 

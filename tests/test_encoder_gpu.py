@@ -347,13 +347,23 @@ def _real_width_hf_and_mine(layers=2, vocab=2048):
                       num_attention_heads=32, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6,
                       max_position_embeddings=1024, rope_parameters={"rope_theta": 1_000_000.0, "rope_type": "default"},
                       attention_bias=False, tie_word_embeddings=False)
-    model = Qwen3Model(hf_cfg).eval()
+    if layers <= 4:
+        model = Qwen3Model(hf_cfg).eval()
+    else:  # 36 layers = 14.5 GB of fp32 parameters: skip the default initialiser, fill in place below
+        with torch.device("meta"):
+            model = Qwen3Model(hf_cfg)
+        model = model.to_empty(device="cpu").float().eval()
+        for mod in model.modules():  # rotary tables are buffers: rebuild them after to_empty
+            if hasattr(mod, "inv_freq") and hasattr(mod, "original_inv_freq"):
+                inv = 1.0 / (1_000_000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+                mod.inv_freq = inv
+                mod.original_inv_freq = inv
     with torch.no_grad():
         for name, p in model.named_parameters():
             if "norm" in name:
                 p.copy_(1 + 0.1 * torch.randn_like(p))
             else:
-                p.copy_(torch.randn_like(p) * 0.02)
+                p.normal_(0.0, 0.02)
             p.copy_(p.to(BF).float())  # both sides hold the same bf16-representable weights
     cfg = Qwen3Config(num_layers=layers, vocab_size=vocab)  # every other field is the 4B default
     assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
@@ -387,6 +397,33 @@ def test_real_width_layers_match_transformers_qwen3(gpu):
     assert diff.pow(2).mean().sqrt() <= 6.5e-4
     assert diff.max() <= 3e-3
     assert cos.min() >= 0.9998
+
+
+def test_full_depth_36_layers_match_transformers_qwen3(gpu):
+    """All 36 layers at the exact 4B widths (the model bench.py times), 2 x 64 tokens + a one-token and a 200-token
+    sequence, against transformers' Qwen3Model in fp32 on the CPU: how the bf16 roundings compound over the depth.
+    A-priori bar, per element of the unit-norm 1024-d output (typical magnitude 1/32): ~12 bf16 roundings per layer
+    of rms relative size 2^-8/sqrt(3) = 2.3e-3, independent => sqrt(36 * 12) * 2.3e-3 = 4.7 % of an element =
+    1.5e-3 rms.  The test allows twice that (3e-3 rms; a network that amplifies perturbations from layer to layer
+    would exceed it), max <= 5 sigma of the bar = 1.5e-2, cosine >= 1 - 1024 * (3e-3)^2 / 2 = 0.9954."""
+    model, enc, cfg = _real_width_hf_and_mine(layers=36)
+    assert len(enc.layers) == 36
+    rng = np.random.default_rng(36)
+    lens = (64, 64, 1, 200)
+    token_lists = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
+    got = enc.embed_token_lists(token_lists).cpu()
+    want = _hf_embed(model, cfg, token_lists, "last")
+    diff = (got - want).abs()
+    cos = (got * want).sum(-1)
+    per_seq = diff.pow(2).mean(dim=1).sqrt()
+    print(f"\n36-layer real-width forward vs transformers fp32: max |d| = {diff.max():.2e}, "
+          f"rms = {diff.pow(2).mean().sqrt():.2e}, min cos = {cos.min():.6f}; per sequence (len: rms): "
+          + ", ".join(f"{n}: {v:.1e}" for n, v in zip(lens, per_seq.tolist())))
+    assert torch.isfinite(got).all() and torch.allclose(got.norm(dim=1), torch.ones(len(lens)), atol=1e-5)
+    assert diff.pow(2).mean().sqrt() <= 3e-3
+    assert diff.max() <= 1.5e-2
+    assert cos.min() >= 0.9954
+    del model
 
 
 def test_backfill_through_native_encoder_into_hbm_index(gpu, monkeypatch):
