@@ -99,6 +99,7 @@ struct crag_index {
         // prepared queries (fragment order) and the prefilter path's per-query state
         DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags;
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
+        uint32_t seq = 0;            // sequence number of the last prefilter search on this workspace (never 0 in use)
         bool done_recorded = false;  // ... once a second stream has appeared (single-stream callers pay no event)
         uint64_t last_use = 0;
     } ws[MAX_WS];
@@ -107,7 +108,6 @@ struct crag_index {
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
     bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false;
-    int env_pf_ablate = 0;
     int env_pf_nt = -1;                       // CRAG_PF_NT=0/1 forces the cache policy of the prefilter scan (developer switch)
     int64_t nt_above_bytes = 1536ll << 20;     // mirror bytes above which its loads stream (measured: no gain below ~1 GB)
     // a stored row whose norm lies outside [1e-30, 1e30]: the fp16 prefilter's error bound assumes normalised
@@ -205,7 +205,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         if ((rc = ws->a16.ensure((size_t)nq_pad * crag::DIM * 2))) return rc;
         {   // n_cu idle records of zeros that nothing ever writes (zeroed once, when the buffer is allocated; at the
             // FRONT, so that no later search with fewer queries finds an old query record there), then the queries'
-            // bound records (zeroed by the prep kernel on every search)
+            // bound records (left zeroed by the selection kernel of every search)
             const size_t need = (size_t)(ix->n_cu + nq_pad) * crag::PF_BOUND_CELLS * sizeof(uint32_t);
             if (need > ws->pf_gbound.bytes) {
                 if ((rc = ws->pf_gbound.ensure(need))) return rc;
@@ -213,8 +213,17 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
             }
         }
         if ((rc = ws->pf_cand.ensure((size_t)nq_pad * cap * sizeof(uint2)))) return rc;
-        if ((rc = ws->pf_count.ensure((size_t)nq_pad * sizeof(uint32_t)))) return rc;
-        if ((rc = ws->pf_flags.ensure(4 * sizeof(uint32_t)))) return rc;
+        {   // per-query candidate counts and the overflow / ticket words: zero when allocated, kept clean by the kernels
+            const size_t need = (size_t)nq_pad * sizeof(uint32_t);
+            if (need > ws->pf_count.bytes) {
+                if ((rc = ws->pf_count.ensure(need))) return rc;
+                HIP_TRY(hipMemsetAsync(ws->pf_count.p, 0, ws->pf_count.bytes, st));
+            }
+            if (ws->pf_flags.bytes == 0) {
+                if ((rc = ws->pf_flags.ensure(4 * sizeof(uint32_t)))) return rc;
+                HIP_TRY(hipMemsetAsync(ws->pf_flags.p, 0, ws->pf_flags.bytes, st));
+            }
+        }
     }
 
     // per-workgroup corpus window must stay below the buffer-descriptor / OOB-marker limit
@@ -246,9 +255,6 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     pp.qinv = (float *)ws->qinv.p;
     pp.a32 = (float *)ws->a32.p;
     pp.a16 = prefilter ? (_Float16 *)ws->a16.p : nullptr;
-    pp.pf_gbound = prefilter ? (uint32_t *)ws->pf_gbound.p + (size_t)ix->n_cu * crag::PF_BOUND_CELLS : nullptr;
-    pp.pf_count = prefilter ? (uint32_t *)ws->pf_count.p : nullptr;
-    pp.pf_flags = prefilter ? (uint32_t *)ws->pf_flags.p : nullptr;
     HIP_TRY(crag::launch_prep_queries(pp, nq_pad, st));
 
     crag::ScanParams sp;
@@ -258,7 +264,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     sp.queries = d_queries;
     sp.a32 = (const float *)ws->a32.p;
     sp.qinv = (const float *)ws->qinv.p;
-    sp.gate = prefilter ? (const uint32_t *)ws->pf_flags.p : nullptr;
+    sp.gate = nullptr;
     sp.dim = ix->dim;
     sp.mask = (const uint32_t *)d_mask;
     sp.mask_stride_w = mask_stride / 4;
@@ -292,8 +298,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         HIP_TRY(hipEventRecord(ev->e1, st));
     }
     if (prefilter) {
-        // K1: fp16 scan -> candidates;  K2: the fp32 scan, which exits at once unless a candidate list
-        // overflowed;  K3: exact rescoring + selection (or the merge of K2's lists)
+        // K1: fp16 scan -> candidates;  K2: exact rescoring + selection, and -- workgroups of the same launch that end
+        // at once unless a candidate list overflowed -- the fp32 fallback scan + merge
         crag::PfParams fp;
         fp.corpus = ix->corpus;
         fp.corpus16 = ix->corpus16;
@@ -307,6 +313,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.cand = (uint2 *)ws->pf_cand.p;
         fp.count = (uint32_t *)ws->pf_count.p;
         fp.flags = (uint32_t *)ws->pf_flags.p;
+        if (++ws->seq == 0u) ws->seq = 1u;
+        fp.seq = ws->seq;
         fp.n_rows = ix->size;
         fp.nq = nq;
         fp.k = k;
@@ -314,7 +322,6 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.reverse = sp.reverse;
         fp.sets = k <= 24 ? 1 : (k <= 48 ? 2 : 4);
         fp.cap = cap;
-        fp.ablate = ix->env_pf_ablate;
         {   // streaming cache policy for a mirror far larger than the Infinity Cache (see prefilter_kernel)
             const int64_t streamed = ix->size * (int64_t)crag::DIM * 2;
             fp.nt = !ix->corpus16 ? 0 : (ix->env_pf_nt >= 0 ? ix->env_pf_nt : (streamed > ix->nt_above_bytes ? 1 : 0));
@@ -322,15 +329,16 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         const int nqb = wide ? 2 : 1;
         HIP_TRY(crag::launch_prefilter(fp, nqb, nq_pad / (32 * nqb), st, &ix->last_scan_kernel));
         if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
-        HIP_TRY(crag::launch_scan(sp, q_blocks, st, nullptr));
         crag::FinParams fin;
         fin.corpus = ix->corpus;
         fin.inv_norm = ix->inv_norm;
         fin.a32 = (const float *)ws->a32.p;
         fin.qinv = (const float *)ws->qinv.p;
         fin.cand = (const uint2 *)ws->pf_cand.p;
-        fin.count = (const uint32_t *)ws->pf_count.p;
+        fin.count = (uint32_t *)ws->pf_count.p;
+        fin.gbound = fp.gbound;
         fin.flags = (const uint32_t *)ws->pf_flags.p;
+        fin.seq = fp.seq;
         fin.ids = ix->ids;
         fin.out_ids = d_out_ids;
         fin.out_scores = d_out_scores;
@@ -339,7 +347,16 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fin.k = k;
         fin.cap = cap;
         fin.merge = mp;
-        HIP_TRY(crag::launch_finalize(fin, nq, st));
+        fin.nq = nq;
+        // the fallback of a search whose candidate list overflows: the self-contained generic scan (32 queries per
+        // pass) inside the same launch, see finalize_fb_kernel
+        sp.wide = 0;
+        sp.gate = nullptr;
+        sp.unpipelined = 1;
+        fin.scan = sp;
+        fin.fb_blocks = G * ((nq + 31) / 32);
+        fin.fb_done = (uint32_t *)ws->pf_flags.p + 1;
+        HIP_TRY(crag::launch_finalize(fin, st));
     } else {
         HIP_TRY(crag::launch_scan(sp, q_blocks, st, &ix->last_scan_kernel));
         if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
@@ -442,7 +459,6 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
     if (const char *v = getenv("CRAG_PF_NT")) ix->env_pf_nt = atoi(v) ? 1 : 0;
-    if (const char *v = getenv("CRAG_PF_ABLATE")) ix->env_pf_ablate = atoi(v);
     if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
         // + 2 KiB per row beside the 4 KiB fp32 row: the prefilter scan then streams half the bytes.  Padding rows

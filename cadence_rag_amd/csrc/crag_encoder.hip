@@ -734,6 +734,108 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, cons
     for (int i = threadIdx.x; i < out_dim; i += blockDim.x) out[(int64_t)b * out_dim + i] = row[i] * inv;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM: out[M, N] = x[M, K] @ W[N, K]^T for M <= 32 tokens -- the encoder at the reference's own operating
+// point, ONE query per /retrieve request (retrieve.py:427).  At that size a linear layer is a WEIGHT STREAM (202 MB of
+// bf16 weights per decoder layer against 16-32 rows of activations): HBM bound, 25 us per layer at 8 TB/s, where the
+// library's GEMM kernels for 16 rows measured ~1 TB/s (profiles/r03_small_encode_kernel_stats.csv).
+//   * weights are stored a second time in MFMA A-fragment order (Qwen3Encoder._small_weights):
+//     wsw[n_tile of 16 rows][k-step of 32][lane = 16 (k/8) + row][8 bf16], so a wave-instruction reads 1 KiB of
+//     contiguous HBM and the loaded registers ARE the A operand of v_mfma_f32_16x16x32_bf16 (rows = output features);
+//   * the activations are the B operand (columns = tokens), each wave keeps the fragments of ITS K range in registers
+//     for the whole kernel (x is 80-300 KB, L2 resident); the K dimension is split over the WAVES waves of a workgroup,
+//     the partial 16x16 tiles are summed through LDS in wave order (deterministic);
+//   * a workgroup owns NT n-tiles; its waves keep 12 weight loads (12 KiB per wave) in flight;
+//   * EPI = 1: the rows of an n-tile are 8 gate rows followed by the 8 up rows of the same features (weights
+//     interleaved that way), and the epilogue writes silu(gate) * up with the model's bf16 roundings (gate and up
+//     rounded to bf16 as a linear layer's output would be, silu in fp32 rounded to bf16, product rounded to bf16).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+struct SkinnyParams {
+    const u16 *x;    // [16 * MG, K] bf16, rows >= m_rows are padding (never stored)
+    const u16 *wsw;  // fragment-ordered weights
+    u16 *out;        // [m_rows, ld_out] bf16
+    int m_rows, n, k, ld_out;
+};
+
+template <int MG, int NT, int KS, int WAVES, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(SkinnyParams p) {
+    __shared__ f32x4_t red[WAVES][NT][MG][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ksteps = p.k >> 5;
+    // activations: B[k = 8 (lane >> 4) + j][col = lane & 15] = x[token 16 mg + (lane & 15)][32 (w KS + s) + 8 (lane >> 4) + j]
+    bf16x8 xb[MG][KS];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg) {
+        const u16 *xr = p.x + (size_t)(16 * mg + (lane & 15)) * p.k + (size_t)w * KS * 32 + 8 * (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xb[mg][s] = *reinterpret_cast<const bf16x8 *>(xr + 32 * s);
+    }
+    constexpr int TOT = NT * KS, D = TOT < 12 ? TOT : 12;
+    const u16 *wbase = p.wsw + ((size_t)blockIdx.x * NT * ksteps + (size_t)w * KS) * 512 + lane * 8;
+    auto wptr = [&](int idx) -> const bf16x8 * {
+        const int nt = idx / KS, s = idx % KS;
+        return reinterpret_cast<const bf16x8 *>(wbase + ((size_t)nt * ksteps + s) * 512);
+    };
+    bf16x8 wr[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(i));
+    f32x4_t acc[NT][MG];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) acc[nt][mg] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TOT; ++i) {
+        const int nt = i / KS, s = i % KS;
+        const bf16x8 wv = wr[i % D];
+        if (i + D < TOT) wr[i % D] = __builtin_nontemporal_load(wptr(i + D));
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg)
+            acc[nt][mg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, xb[mg][s], acc[nt][mg], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) red[w][nt][mg][lane] = acc[nt][mg];
+    __syncthreads();
+    // D[row = 4 (lane >> 4) + reg][col = lane & 15]: a (tile, token group, lane) unit = 4 consecutive features of one token
+    constexpr int UNITS = NT * MG * 64;
+    for (int u = threadIdx.x; u < UNITS; u += WAVES * 64) {
+        const int l = u & 63, mg = (u >> 6) % MG, nt = (u >> 6) / MG;
+        const int token = 16 * mg + (l & 15);
+        if (EPI == 1 && l >= 32) continue;  // the up half is consumed by the thread of its gate half
+        f32x4_t sum = red[0][nt][mg][l];
+#pragma unroll
+        for (int ww = 1; ww < WAVES; ++ww) sum += red[ww][nt][mg][l];
+        if (token >= p.m_rows) continue;
+        const int tile = (int)blockIdx.x * NT + nt;
+        if (EPI == 0) {
+            u16 o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = f2bf(sum[r]);
+            *reinterpret_cast<uint2 *>(p.out + (size_t)token * p.ld_out + 16 * tile + 4 * (l >> 4)) =
+                make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        } else {
+            f32x4_t up = red[0][nt][mg][l + 32];
+#pragma unroll
+            for (int ww = 1; ww < WAVES; ++ww) up += red[ww][nt][mg][l + 32];
+            u16 o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float g = bf2f(f2bf(sum[r]));
+                const float act = bf2f(f2bf(g / (1.f + __expf(-g))));
+                o[r] = f2bf(act * bf2f(f2bf(up[r])));
+            }
+            *reinterpret_cast<uint2 *>(p.out + (size_t)token * p.ld_out + 8 * tile + 4 * (l >> 4)) =
+                make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -840,6 +942,42 @@ int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *d
     hipLaunchKernelGGL(pool_normalize_kernel, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, hidden_states,
                        delta, final_norm_w, cu_seqlens, out, hidden, out_dim, mode, eps);
     return hip_ok("pool_normalize");
+}
+
+int crag_enc_skinny_gemm(const uint16_t *x, const uint16_t *wsw, uint16_t *out, int m_rows, int m_pad, int n, int k,
+                         int epilogue, void *stream) {
+    if (!x || !wsw || !out) return efail("skinny_gemm: NULL pointer");
+    if (m_rows <= 0 || m_rows > m_pad || (m_pad != 16 && m_pad != 32)) return efail("skinny_gemm: m_pad must be 16 or 32 and m_rows <= m_pad");
+    if (epilogue != 0 && epilogue != 1) return efail("skinny_gemm: epilogue must be 0 or 1");
+    if (n <= 0 || (n & 15)) return efail("skinny_gemm: n must be a positive multiple of 16");
+    SkinnyParams p;
+    p.x = x;
+    p.wsw = wsw;
+    p.out = out;
+    p.m_rows = m_rows;
+    p.n = n;
+    p.k = k;
+    p.ld_out = epilogue ? n / 2 : n;
+    const int tiles = n / 16;
+    hipStream_t st = (hipStream_t)stream;
+#define CRAG_SKINNY(MG_, NT_, KS_, WAVES_, EPI_)                                                              \
+    hipLaunchKernelGGL((skinny_gemm_kernel<MG_, NT_, KS_, WAVES_, EPI_>), dim3((unsigned)(tiles / NT_)),      \
+                       dim3(WAVES_ * 64), 0, st, p)
+    const int mg = m_pad / 16;
+    if (k == 2560 && epilogue == 0) {
+        if (mg == 1) CRAG_SKINNY(1, 1, 10, 8, 0); else CRAG_SKINNY(2, 1, 10, 8, 0);
+    } else if (k == 2560 && epilogue == 1) {
+        if (tiles & 1) return efail("skinny_gemm: the SwiGLU form needs an even number of n-tiles");
+        if (mg == 1) CRAG_SKINNY(1, 2, 10, 8, 1); else CRAG_SKINNY(2, 2, 10, 8, 1);
+    } else if (k == 4096 && epilogue == 0) {
+        if (mg == 1) CRAG_SKINNY(1, 1, 16, 8, 0); else CRAG_SKINNY(2, 1, 16, 8, 0);
+    } else if (k == 9728 && epilogue == 0) {
+        if (mg == 1) CRAG_SKINNY(1, 1, 38, 8, 0); else CRAG_SKINNY(2, 1, 19, 16, 0);
+    } else {
+        return efail("skinny_gemm: unsupported shape k=%d epilogue=%d (built for the Qwen3-Embedding-4B widths: k = 2560 / 4096 / 9728)", k, epilogue);
+    }
+#undef CRAG_SKINNY
+    return hip_ok("skinny_gemm");
 }
 
 }  // extern "C"

@@ -62,9 +62,6 @@ struct PrepParams {
     float *qinv;              // [nq_pad]
     float *a32;               // [nq_pad/32][8 waves][16][64] float4: raw queries in fp32 A-fragment order
     _Float16 *a16;            // nullable; [nq_pad/32][8 waves][8][64][8]: unit queries in fp16 A-fragment order
-    uint32_t *pf_gbound;      // nullable; [nq_pad][PF_BOUND_CELLS], zeroed here
-    uint32_t *pf_count;       // [nq_pad] candidates per query, zeroed here
-    uint32_t *pf_flags;       // [4]: [0] = a candidate list overflowed, zeroed here
 };
 
 struct PfParams {
@@ -79,13 +76,13 @@ struct PfParams {
     const uint32_t *gbound_idle;  // [>= G][PF_BOUND_CELLS] zeros that nothing writes: where the loads of dead queries go
     uint2 *cand;              // [nq_pad][cap]: x = orderable approximate score, y = row position
     uint32_t *count;          // [nq_pad]
-    uint32_t *flags;
+    uint32_t *flags;          // [0] = sequence number of the search whose candidate list overflowed, [1] = fallback tickets
+    uint32_t seq;             // this search's sequence number on its workspace (never 0)
     int64_t n_rows;
     int nq, k, G, reverse;
     int sets;                 // 1, 2 or 4 class sets (<= k)
     int nt;                   // corpus loads with the streaming cache policy (corpus larger than the Infinity Cache)
     int cap;
-    int ablate;               // developer switch (CRAG_PF_ABLATE): parts of the kernel switched off for timing, results invalid
 };
 
 struct FinParams {
@@ -94,15 +91,23 @@ struct FinParams {
     const float *a32;
     const float *qinv;
     const uint2 *cand;
-    const uint32_t *count;
+    uint32_t *count;            // [nq_pad]; zeroed per query after use
+    uint32_t *gbound;           // [nq_pad][PF_BOUND_CELLS]; zeroed per query after use
     const uint32_t *flags;
+    uint32_t seq;
     const int64_t *ids;
     int64_t *out_ids;
     float *out_scores;
     int32_t *out_counts;
     unsigned long long *stats;  // nullable; PF_STAT_SLOTS records {candidates, rescored rows, searches}, record q % SLOTS
     int k, cap;
-    MergeParams merge;          // used instead when flags[0] != 0 (the gated fp32 scan ran)
+    int nq;                     // selection blocks of the launch: [0, nq)
+    // fallback role (flags[0] != 0: a candidate list overflowed): fb_blocks = scan.G * ceil(nq / 32) workgroups behind
+    // the selection blocks run the exact fp32 scan, the one that finishes last merges
+    int fb_blocks;
+    uint32_t *fb_done;          // ticket counter, zero between searches
+    ScanParams scan;
+    MergeParams merge;
 };
 
 struct XMergeParams {
@@ -123,7 +128,7 @@ hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st, const 
 hipError_t launch_prep_queries(const PrepParams &p, int nq_pad, hipStream_t st);
 // passes = number of 32*nqb-query passes (grid.y); nqb = 1 or 2
 hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t st, const char **kernel_name);
-hipError_t launch_finalize(const FinParams &p, int nq, hipStream_t st);
+hipError_t launch_finalize(const FinParams &p, hipStream_t st);
 hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st);
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,

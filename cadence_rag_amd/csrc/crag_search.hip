@@ -179,12 +179,12 @@ struct ScanCtx {
 };
 
 // row range / lane geometry of one scan workgroup (everything but the query fields)
-__device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int reverse) {
+__device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int reverse, int g, int qb) {
     ScanCtx c;
     c.lane = threadIdx.x & 63;
     c.w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    c.g = blockIdx.x;
-    c.qb = blockIdx.y;
+    c.g = g;
+    c.qb = qb;
     c.j = c.lane & 31;
     c.h = c.lane >> 5;
     // this workgroup's row range, balanced in units of 8 rows (one 128-B line per k-quad)
@@ -203,8 +203,9 @@ __device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int rever
     return c;
 }
 
-__device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p) {
-    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse);
+// (g, qb): the workgroup's position in the scan grid -- blockIdx.x / .y of a stand-alone scan kernel
+__device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p, int g, int qb) {
+    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse, g, qb);
     // after the LDS reduction this wave holds accumulator registers r = 2w, 2w+1 ->
     // query (r&3) + 8*(r>>2) + 4*h of the block, corpus row j of the tile
 #pragma unroll
@@ -238,12 +239,46 @@ __device__ __forceinline__ uint32_t tile_voff(const ScanCtx &c, int step) {
     return valid ? (uint32_t)ti * (uint32_t)(TILE_FLOATS * 4) + c.lane_off : 0x80000000u;
 }
 
-// A operand: this wave's K slice of the (up to) 32 queries of block qb, normalised in-kernel.
-// Lane (i = lane&31, h = lane>>5) holds q[i][128w + 8s + 4h + 0..3] in a[s] — the same k
-// permutation the tile32 corpus layout gives the B operand.  A zero / non-finite query becomes
-// NaN so none of its scores is ever eligible.  `red` is 2 KiB of LDS scratch.
-__device__ __forceinline__ void load_queries(const ScanParams &p, const ScanCtx &c, f32x4 (&a)[16],
-                                             double *red) {
+// ---- the canonical 1/||q||: ONE piece of arithmetic for every kernel that needs a query's norm -------------------
+// Thread t < 256 holds dims 4t .. 4t+3 of the query (zeros beyond dim / for threads >= 256); squares in fp64, a
+// butterfly sum inside each of the first four waves, the four wave sums added in wave order.  prep_queries_kernel,
+// the selection kernel and the fallback scan all call this, so the exact scores (x 1/||row|| x 1/||q||) are the same
+// bits on every path.  All threads of the workgroup must call it (two barriers); sh: 4 doubles of LDS.
+__device__ __forceinline__ f32x4 load_query_quad(const float *queries, int dim, int q, int nq, int t) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq && t < 256) {
+        const float *src = queries + (size_t)q * dim;
+        if ((dim & 3) == 0) {
+            if (4 * t < dim) v = *reinterpret_cast<const f32x4 *>(src + 4 * t);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * t + c < dim) v[c] = src[4 * t + c];
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ float canonical_qinv(const f32x4 v, bool real_query, double *sh) {
+    double ss = ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0 && wv < 4) sh[wv] = ss;
+    __syncthreads();
+    const double tot = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    const bool ok = real_query && (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
+    float qinv = ok ? (float)(1.0 / sqrt(tot)) : 0.f;
+    if (!(qinv < 3.0e38f)) qinv = 0.f;
+    return qinv;
+}
+
+// A operand of the generic kernel: this wave's K slice of the (up to) 32 RAW queries of block qb; lane (i = lane&31,
+// h = lane>>5) holds q[i][128w + 8s + 4h + 0..3] in a[s] -- the same k permutation the tile32 corpus layout gives
+// the B operand.  qinv_s[32] (LDS) receives the canonical 1/||q|| of the block's queries (0: zero / non-finite /
+// missing query, never eligible); sh: 4 doubles of LDS.  All threads of the workgroup call this.
+__device__ __forceinline__ void load_queries(const ScanParams &p, const ScanCtx &c, f32x4 (&a)[16], float *qinv_s,
+                                             double *sh) {
     const int qi = c.qb * 32 + c.j;
     const bool have = qi < p.nq;
     const float *qrow = p.queries + (size_t)(have ? qi : 0) * p.dim;
@@ -262,32 +297,21 @@ __device__ __forceinline__ void load_queries(const ScanParams &p, const ScanCtx 
         }
         a[s] = v;
     }
-    double ss = 0.0;
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ss += (double)a[s][cc] * (double)a[s][cc];
-    ss += __shfl_xor(ss, 32);
-    if (c.h == 0) red[c.w * 32 + c.j] = ss;
+    for (int i = 0; i < 32; ++i) {  // (32 x two barriers: this kernel is the rare path / the A-B baseline)
+        const int q = c.qb * 32 + i;
+        const float r = canonical_qinv(load_query_quad(p.queries, p.dim, q, p.nq, (int)threadIdx.x), q < p.nq, sh);
+        if (threadIdx.x == 0) qinv_s[i] = r;
+    }
     __syncthreads();
-    double tot = 0.0;
-#pragma unroll
-    for (int ww = 0; ww < SCAN_WAVES; ++ww) tot += red[ww * 32 + c.j];
-    __syncthreads();
-    const bool ok = (tot > 0.0) && (tot < 1.0e300) && (tot == tot);
-    const double inv = ok ? 1.0 / sqrt(tot) : (double)__uint_as_float(0x7fc00000u);
-#pragma unroll
-    for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) a[s][cc] = (float)((double)a[s][cc] * inv);
 }
 
 // score -> key for one owned (query, row) pair
-__device__ __forceinline__ void make_key(float dot, float inv_row, bool ok, int64_t row, uint32_t &khi,
-                                         uint32_t &klo) {
-    float sc = dot * inv_row;
-    sc = fminf(fmaxf(sc, -1.f), 1.f);  // pgvector clamps the similarity to [-1, 1]
-    ok = ok && (dot == dot);
+// (the pipelined kernels' and the selection kernel's expression, so that all of them produce the same bits:
+// scale = 1/||row|| * 1/||q||, or 0 when the pair is not eligible)
+__device__ __forceinline__ void make_key(float dot, float scale, int64_t row, uint32_t &khi, uint32_t &klo) {
+    float sc = dot * scale;
+    sc = __builtin_amdgcn_fmed3f(sc, -1.f, 1.f);  // pgvector clamps the similarity to [-1, 1]
+    const bool ok = (scale > 0.f) && (sc == sc);
     khi = ok ? f2ord(sc) : 0u;
     klo = ok ? ~(uint32_t)row : 0u;
 }
@@ -309,10 +333,12 @@ __device__ __forceinline__ void write_lists(const ScanParams &p, const ScanCtx &
 #define CRAG_MFMA(A_, B_, ACC_) __builtin_amdgcn_mfma_f32_32x32x2f32((A_), __uint_as_float(B_), (ACC_), 0, 0, 0)
 
 // ---- generic kernel (any S): MFMA phase, then reduction + selection, one barrier per tile ----
+// The body is a device function so that the prefilter path's selection kernel can run it as its fallback (workgroups
+// of the same launch, see finalize_fb_kernel): slab = 64 KiB of LDS, [buf][producer wave][reg pair][lane].
 template <int S>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
-    __shared__ float2 slab[2][SCAN_WAVES][8][64];  // 64 KiB: [buf][producer wave][reg pair][lane]
-    const ScanCtx c = make_ctx(p);
+__device__ __forceinline__ void scan_body(const ScanParams &p, const int g, const int qb,
+                                          float2 (*slab)[SCAN_WAVES][8][64]) {
+    const ScanCtx c = make_ctx(p, g, qb);
     const int lane = c.lane, w = c.w, j = c.j;
 
     const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
@@ -326,7 +352,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
         for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff(s), 0, 0);
     }
     f32x4 a[16];
-    load_queries(p, c, a, reinterpret_cast<double *>(&slab[0][0][0][0]));
+    float qinv[2];
+    {   // LDS scratch inside the (still unused) slab: 32 floats + 4 doubles
+        float *qinv_s = reinterpret_cast<float *>(&slab[0][0][0][0]);
+        load_queries(p, c, a, qinv_s, reinterpret_cast<double *>(qinv_s + 32));
+        qinv[0] = qinv_s[c.qloc[0]];
+        qinv[1] = qinv_s[c.qloc[1]];
+        __syncthreads();  // the slab is about to be written
+    }
     // drain with the compiler's own builtin so its vmcnt scoreboard is empty at the loop head:
     // otherwise the loop-head merge keeps a conservative wait on the A registers in every
     // iteration and drains the prefetch ring
@@ -375,11 +408,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             uint32_t khi, klo;
-            make_key(d[e], inv_cur, row_ok && c.qok[e] && ((mword[e] >> j) & 1u), row, khi, klo);
+            make_key(d[e], (row_ok && c.qok[e] && ((mword[e] >> j) & 1u)) ? inv_cur * qinv[e] : 0.f, row, khi, klo);
             list[e].insert(khi, klo, p.k, lane);
         }
     }
     write_lists<S>(p, c, list);
+}
+
+template <int S>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
+    __shared__ float2 slab[2][SCAN_WAVES][8][64];
+    scan_body<S>(p, blockIdx.x, blockIdx.y, slab);
 }
 
 // Few candidates (the common case once the thresholds have tightened): insert them one by one into the
@@ -621,7 +660,7 @@ __device__ __forceinline__ uint32_t half_min_u32(uint32_t v) {
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     __shared__ float2 slab[2][SCAN_WAVES][8][64];
     if (p.gate && *p.gate == 0u) return;  // fallback launch behind the prefilter path: nothing overflowed
-    const ScanCtx c = make_ctx(p);
+    const ScanCtx c = make_ctx(p, blockIdx.x, blockIdx.y);
     const int lane = c.lane, w = c.w, j = c.j;
 
     const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
@@ -962,7 +1001,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
     if (p.gate && *p.gate == 0u) return;  // fallback launch behind the prefilter path: nothing overflowed
     constexpr int RING = NQB == 2 ? 8 : 16;   // B prefetch ring depth (loads in flight per wave)
     constexpr int SLOTS = 64 * NQB;           // MFMAs per tile and wave
-    const ScanCtx c = make_ctx(p);  // row range; its query fields are not used here
+    const ScanCtx c = make_ctx(p, blockIdx.x, blockIdx.y);  // row range; its query fields are not used here
     const int lane = c.lane, w = c.w, j = c.j;
     Pipe2Ctx<NQB> c2;
     c2.bucket = c.g % p.nb;
@@ -1559,27 +1598,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- K0: per query 1/||q||, the query in fp32 A-fragment order (raw) and fp16 A-fragment order (unit) --------
-// One 256-thread workgroup per padded query; thread t owns dims 4t .. 4t+3.  Also resets the per-query
-// prefilter state (class maxima, candidate count) and the overflow flag of this workspace.
+// One 256-thread workgroup per padded query; thread t owns dims 4t .. 4t+3.  (The per-query prefilter state --
+// class maxima, candidate count -- is left zeroed by the selection kernel of the previous search; the overflow
+// word holds the sequence number of the search that overflowed and needs no reset.)
 __global__ __launch_bounds__(256) void prep_queries_kernel(PrepParams p) {
     __shared__ double sh[4];
     const int q = blockIdx.x, t = threadIdx.x;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (q < p.nq) {
-        const float *src = p.queries + (size_t)q * p.dim;
-        if ((p.dim & 3) == 0) {
-            if (4 * t < p.dim) v = *reinterpret_cast<const f32x4 *>(src + 4 * t);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (4 * t + c < p.dim) v[c] = src[4 * t + c];
-        }
-    }
-    double ss = ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
-    ss = block_sum_256(ss, sh);
-    const bool ok = (q < p.nq) && (ss > 0.0) && (ss < 1.0e300) && (ss == ss);
-    float qinv = ok ? (float)(1.0 / sqrt(ss)) : 0.f;
-    if (!(qinv < 3.0e38f)) qinv = 0.f;
+    const f32x4 v = load_query_quad(p.queries, p.dim, q, p.nq, t);
+    const float qinv = canonical_qinv(v, q < p.nq, sh);
     if (t == 0) p.qinv[q] = qinv;
     const int qb = q >> 5, i = q & 31, w = t >> 5, d = (4 * t) & 127;
     {   // fp32 fragments: float4 (s, h) of wave slice w, s = d/8, h = (d/4)&1
@@ -1593,11 +1619,6 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(PrepParams p) {
         _Float16 *dst = p.a16 + ((((size_t)(qb * SCAN_WAVES + w) * 8 + t8) * 64 + h * 32 + i) * 8 + 4 * g);
         typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<f16x4 *>(dst) = f16x4{l2[0], l2[1], h2[0], h2[1]};
-    }
-    if (p.pf_gbound) {
-        if (t < PF_BOUND_CELLS) p.pf_gbound[(size_t)q * PF_BOUND_CELLS + t] = 0u;
-        if (t == 0) p.pf_count[q] = 0u;
-        if (q == 0 && t < 4) p.pf_flags[t] = 0u;
     }
 }
 
@@ -1656,7 +1677,7 @@ struct PfOwner {
 // candidates of one tile -> LDS staging.  sc: approximate cosines (NaN = not eligible), pass: candidate predicate
 template <int NQB>
 __device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, const float (&sc)[2 * NQB],
-                                         const bool (&pass)[2 * NQB], uint32_t row_in_window, uint32_t *flags) {
+                                         const bool (&pass)[2 * NQB], uint32_t row_in_window, uint32_t *flags, uint32_t seq) {
 #pragma unroll
     for (int e = 0; e < 2 * NQB; ++e) {
         if (pass[e]) {
@@ -1665,7 +1686,7 @@ __device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, c
                 atomicAdd(&L.qcount[o.ql0 + e], 1u);
                 L.stage[slot] = make_uint2(f2ord(sc[e]), (row_in_window << 6) | (uint32_t)(o.ql0 + e));
             } else {
-                *flags = 1u;  // cannot happen (<= PF_FLUSH_ABOVE staged + <= 2048 per tile); never drop one silently
+                *flags = seq;  // cannot happen (<= PF_FLUSH_ABOVE staged + <= 2048 per tile); never drop one silently
             }
         }
     }
@@ -1678,7 +1699,7 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
     __syncthreads();
     const uint32_t n = L.n_stage < (uint32_t)PF_STAGE ? L.n_stage : (uint32_t)PF_STAGE;
     const int tid = threadIdx.x;
-    if (LAST && (n == 0u || (p.ablate & 1))) return;  // (uniform)
+    if (LAST && n == 0u) return;  // (uniform)
     if (tid < 32 * NQB) {
         const uint32_t cnt = L.qcount[tid];
         const int qg = (int)blockIdx.y * (32 * NQB) + tid;
@@ -1695,7 +1716,7 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
         if (pos < (uint32_t)p.cap) {
             p.cand[(size_t)qg * p.cap + pos] = make_uint2(e.x, (uint32_t)(window_row0 + (int64_t)(e.y >> 6)));
         } else {
-            p.flags[0] = 1u;  // this query's list is full: the exact scan behind us takes over
+            p.flags[0] = p.seq;  // this query's list is full: the fallback blocks of the selection launch take over
         }
     }
     if (LAST) return;
@@ -1781,7 +1802,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
     // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
     f16x8 a[NQB][8];
-    if (!(p.ablate & 16)) {
+    PfOwner<NQB> o;
+    {
+        const int R = w * RPO, qb = R >> 4, r = R & 15;
+        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
+        o.okmask = 0u;
+    }
+    {
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) {
             const f16x8 *af = reinterpret_cast<const f16x8 *>(p.a16) +
@@ -1789,23 +1817,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 #pragma unroll
             for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = af[t8 * 64];
         }
-    } else {
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-            for (int t8 = 0; t8 < 8; ++t8) a[qb][t8] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-
-    PfOwner<NQB> o;
-    {
-        const int R = w * RPO, qb = R >> 4, r = R & 15;
-        o.ql0 = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        o.qg0 = (int)blockIdx.y * (32 * NQB) + o.ql0;
         // the RPO owned queries are consecutive and qg0 is a multiple of RPO: one aligned vector load (qinv is
         // nq_pad long; padded queries hold 0)
         typedef float qv_t __attribute__((ext_vector_type(RPO)));
         const qv_t qi = *reinterpret_cast<const qv_t *>(p.qinv + o.qg0);
-        o.okmask = 0u;
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
             if (o.qg0 + e < p.nq && qi[e] > 0.f) o.okmask |= 1u << e;
@@ -1880,7 +1895,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         const uint32_t vnext = voff(ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
-        const bool rd = ti == next_read && !(p.ablate & 4);  // uniform
+        const bool rd = ti == next_read;  // uniform
         // operands of this tile's epilogue, behind the B loads of this tile (in flight) and in front of the next one's
         float inv_nxt = 1.f;
         if constexpr (!MIRROR) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1 < c.n_tiles ? ti + 1 : ti)) * 32 + j];
@@ -1977,7 +1992,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                     lmax[e][s] = ord;
                     dirty |= 1u << (e * SETS + s);
                 }
-            pass[e] = sc[e] >= thr[e] && !(p.ablate & 8);
+            pass[e] = sc[e] >= thr[e];
         }
         if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
 #pragma unroll
@@ -1988,7 +2003,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) stash2[e] = sc[e];
             stash2_row = (uint32_t)(row - c.t_begin * 32);
         } else {
-            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags);
+            pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags, p.seq);
         }
         if (ti == next_pub) {  // uniform
 #pragma unroll
@@ -2009,7 +2024,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                             lift = lift && (v >= (uint32_t)__shfl((int)sorted, (lane & 32) | (SETS - 1)));
                         }
                     }
-                    if (lift && !(p.ablate & 2))
+                    if (lift)
                         (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + s * 32, v, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -2044,12 +2059,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         }
         bool pass[RPO];
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e] && !(p.ablate & 8);
-        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags);
+        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
+        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags, p.seq);
         flush_if_full();
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e] && !(p.ablate & 8);
-        pf_stage<NQB>(L, o, stash2, pass, stash2_row, p.flags);
+        for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e];
+        pf_stage<NQB>(L, o, stash2, pass, stash2_row, p.flags, p.seq);
     }
     pf_flush<NQB, true>(p, L, c.t_begin * 32);
 }
@@ -2061,7 +2076,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 //    the fmaf chain of v_mfma_f32_32x32x2_f32 in the kernels' k order, the 8 slice sums added in wave order,
 //    x (1/||row|| * 1/||q||), clamp -- so scores and order are bit-identical to the fp32 scan.
 // 3. rank by counting among the exact keys.
-// When the prefilter scan reported an overflow the gated fp32 scan has filled p.partial instead: merge that.
 constexpr int FIN_ROUND = 4096;             // candidates examined per round (all of them, for k <= 128 on the bench's corpora)
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
@@ -2091,25 +2105,85 @@ __device__ __forceinline__ float exact_slice_dot(const f32x4 *qslice /* [16][2] 
     return acc;
 }
 
-__global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
-    __shared__ uint64_t best[FIN_BEST];
-    __shared__ uint2 lcand[FIN_ROUND];     // the candidates of the common case (all of them fit): x = score, y = row
-    __shared__ uint32_t surv[FIN_ROUND];   // rows to rescore in the current round
-    __shared__ f32x4 qs[SCAN_WAVES][16][2];  // the query in fragment order: [slice][s][lane half]
-    __shared__ int64_t best_id[FIN_BEST];  // external id of best[i]'s row, fetched beside the row itself
-    __shared__ unsigned long long hist[32];  // exchange buffer of the workgroup reductions
-    __shared__ int s_nbest, s_nsurv, s_rescored;
-    __shared__ uint32_t s_kth;
+// LDS of the selection role; the fallback role's split-K slab (64 KiB) shares the same bytes
+struct FinLds {
+    uint64_t best[FIN_BEST];
+    uint2 lcand[FIN_ROUND];       // the candidates of the common case (all of them fit): x = score, y = row
+    uint32_t surv[FIN_ROUND];     // rows to rescore in the current round
+    f32x4 qs[SCAN_WAVES][16][2];  // the query in fragment order: [slice][s][lane half]
+    int64_t best_id[FIN_BEST];    // external id of best[i]'s row, fetched beside the row itself
+    unsigned long long hist[32];  // exchange buffer of the workgroup reductions
+    int s_nbest, s_nsurv, s_rescored;
+    uint32_t s_kth;
+};
+union FinFbLds {
+    FinLds f;
+    float2 slab[2][SCAN_WAVES][8][64];
+};
+
+// ONE launch behind the prefilter scan, two kinds of workgroups (512 threads each):
+//  * blocks [0, nq): selection.  Waves 0-3 do the work described above, waves 4-7 end at once.
+//  * blocks [nq, nq + fb_blocks): the FALLBACK for a search whose candidate list overflowed (thousands of rows within
+//    2 delta of the k-th best: boilerplate chunks embed identically).  They end at once unless the overflow flag is
+//    set; then each runs the exact fp32 scan of its row range (scan_body: self-contained, it normalises the raw
+//    queries itself), and the workgroup that finishes LAST merges the partial lists of every query -- no workgroup
+//    ever waits for another one, so nothing can deadlock; the selection blocks of such a search write nothing.
+//    [Round 2 launched the fallback as a kernel of its own between scan and selection, gated by the flag: 256 heavy
+//    workgroups created and torn down per search to read one word, 2.1-2.6 us + a kernel boundary.]
+//  * Both roles leave the workspace clean: the selection block of query q zeroes the query's candidate count and
+//    class maxima when it is done with them (the next search's scan finds zeros); the overflow word holds the
+//    SEQUENCE NUMBER of the search that overflowed (never reset: the next search compares with its own number).
+template <int S>
+__global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) {
+    __shared__ FinFbLds U;
+    __shared__ int s_last;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if ((int)blockIdx.x >= p.nq) {
+        if (__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq) return;
+        const int b = (int)blockIdx.x - p.nq;
+        scan_body<S>(p.scan, b % p.scan.G, b / p.scan.G, U.slab);
+        // every wave's list stores are drained at the barrier; one lane releases them and draws a ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t t = __hip_atomic_fetch_add(p.fb_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == (uint32_t)(p.fb_blocks - 1)) ? 1 : 0;
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (!s_last || wave >= MERGE_THREADS / 64) return;   // (whole waves end: the barriers below count the rest)
+        for (int q = 0; q < p.nq; ++q) {
+            merge_partials_body(p.merge, q);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(p.fb_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (wave >= MERGE_THREADS / 64) return;
+    auto &best = U.f.best;
+    auto &lcand = U.f.lcand;
+    auto &surv = U.f.surv;
+    auto &qs = U.f.qs;
+    auto &best_id = U.f.best_id;
+    auto &hist = U.f.hist;
+    int &s_nbest = U.f.s_nbest, &s_nsurv = U.f.s_nsurv, &s_rescored = U.f.s_rescored;
+    uint32_t &s_kth = U.f.s_kth;
     const int q = blockIdx.x, tid = threadIdx.x;
     // Everything the kernel needs first, in flight together (one memory round trip instead of a chain of four:
     // flag -> count -> candidates -> ...): the overflow flag, the candidate count, the first MERGE_THREADS
     // candidates (read before the count is known -- the list has `cap` >= MERGE_THREADS slots; the usual few dozen
     // candidates are all among them), the query's norm and its fp32 fragments.
     const uint2 *gcand = p.cand + (size_t)q * p.cap;
-    const uint32_t overflow = p.flags[0];
+    const bool overflow = p.flags[0] == p.seq;
     const uint32_t total = p.count[q];
     const uint2 first = gcand[tid];
     const float qinv = p.qinv[q];
+    // thread t = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
+    const f32x4 qfrag = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + (tid >> 5)) * 16 + ((tid >> 1) & 15)) * 64 + (tid & 1) * 32 + (q & 31)];
     // Statistics (bench.py's byte accounting): a record per query that only this workgroup updates -- read here,
     // written back at the end with plain stores.  [They were three atomic adds on one shared record: 192 same-line
     // device-scope atomics per search, whose acknowledgements the kernel's end had to wait for.]  Searches of more
@@ -2121,10 +2195,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
         stat_old[1] = stat[1];
         stat_old[2] = stat[2];
     }
-    // thread t = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
-    const f32x4 qfrag = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + (tid >> 5)) * 16 + ((tid >> 1) & 15)) * 64 + (tid & 1) * 32 + (q & 31)];
-    if (overflow != 0u) {  // uniform over the grid
-        merge_partials_body(p.merge, q);
+    // the scan is over: leave the query's state zeroed for the next search on this workspace (the count only once
+    // every thread has its copy: behind the first barrier below)
+    if (tid < PF_BOUND_CELLS) p.gbound[(size_t)q * PF_BOUND_CELLS + tid] = 0u;
+    if (overflow) {  // (uniform over the grid) the fallback blocks of this launch answer this search
+        if (tid == 0) p.count[q] = 0u;
         return;
     }
     const int k = p.k;
@@ -2140,6 +2215,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void finalize_kernel(FinParams p) {
         s_kth = 0u;
     }
     __syncthreads();
+    if (tid == 0) p.count[q] = 0u;
 
     // 1. k-th largest approximate score among the candidates
     uint32_t thr_ord = 0u;
@@ -2428,8 +2504,12 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const FinParams &p, int nq, hipStream_t st) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(nq), dim3(MERGE_THREADS), 0, st, p);
+hipError_t launch_finalize(const FinParams &p, hipStream_t st) {
+    const dim3 grid(p.nq + p.fb_blocks), block(SCAN_THREADS);
+    const int ks = (p.k + 31) / 32;  // list slots of the fallback scan
+    if (ks == 1) hipLaunchKernelGGL(finalize_fb_kernel<1>, grid, block, 0, st, p);
+    else if (ks == 2) hipLaunchKernelGGL(finalize_fb_kernel<2>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(finalize_fb_kernel<4>, grid, block, 0, st, p);
     return hipGetLastError();
 }
 

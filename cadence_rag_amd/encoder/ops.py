@@ -77,3 +77,29 @@ def pool_normalize(hidden_states, final_norm_w, cu, out, out_dim: int, mode: int
                                                              _p(out), cu.numel() - 1, hidden_states.shape[1], out_dim,
                                                              mode, float(eps), _stream()), "crag_enc_pool_normalize")
     return out
+
+
+def skinny_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[n, k] bf16 (torch Linear layout) -> the MFMA A-fragment order crag_enc_skinny_gemm streams
+    ([n/16][k/32][lane = 16 (kk/8) + row][8]); n % 16 == 0, k % 32 == 0."""
+    n, k = weight.shape
+    return weight.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def skinny_gate_up_weight(gate_up: torch.Tensor) -> torch.Tensor:
+    """The fused [2I, k] gate|up weight with rows interleaved per 8 features (tile t = gate rows 8t..8t+7, then up rows
+    8t..8t+7), in fragment order: the operand of skinny_gemm(..., swiglu=True)."""
+    two_i, k = gate_up.shape
+    inter = two_i // 2
+    g = gate_up[:inter].view(inter // 8, 8, k)
+    u = gate_up[inter:].view(inter // 8, 8, k)
+    return skinny_weight(torch.cat([g, u], dim=1).reshape(two_i, k))
+
+
+def skinny_gemm(x: torch.Tensor, wsw: torch.Tensor, out: torch.Tensor, m_rows: int, n: int, swiglu: bool = False):
+    """out[m_rows, n (or n/2)] = x[m_pad, k] @ W^T for m_pad = 16 or 32 token rows (crag_enc_skinny_gemm)."""
+    _req(x, torch.bfloat16, "x"); _req(wsw, torch.bfloat16, "wsw"); _req(out, torch.bfloat16, "out")
+    m_pad, k = x.shape
+    _native.check(_native.load().crag_enc_skinny_gemm(_p(x), _p(wsw), _p(out), int(m_rows), int(m_pad), int(n), int(k),
+                                                      1 if swiglu else 0, _stream()), "crag_enc_skinny_gemm")
+    return out

@@ -221,6 +221,21 @@ class Qwen3Encoder:
         enc.tokenizer = AutoTokenizer.from_pretrained(str(root), local_files_only=True)
         return enc
 
+    # -- 16 / 32 tokens: the linear layers as weight streams ------------------------------------------------
+    def _skinny_weights(self) -> Optional[List[Dict[str, torch.Tensor]]]:
+        """The four projections of every layer a second time, in the fragment order crag_enc_skinny_gemm streams
+        (+ 100 % of the layer weights in HBM: 8 GB for the 4B model), built on first use.  None when the model's
+        widths are not the ones the kernel is built for or CRAG_ENC_NO_SKINNY is set."""
+        c = self.cfg
+        if (os.environ.get("CRAG_ENC_NO_SKINNY") is not None or c.hidden_size != 2560 or c.q_size != 4096
+                or c.intermediate_size != 9728 or (c.q_size + 2 * c.kv_size) % 16):
+            return None
+        if self.__dict__.get("_skinny") is None:
+            self._skinny = [{"qkv": ops.skinny_weight(L["qkv"]), "o": ops.skinny_weight(L["o"]),
+                             "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.skinny_weight(L["down"])}
+                            for L in self.layers]
+        return self._skinny
+
     # -- forward --------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_packed(self, ids: torch.Tensor, batch: PackedBatch) -> torch.Tensor:
@@ -242,6 +257,8 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
+        # 16 or 32 tokens (one short query): the projections stream their weights through crag_enc_skinny_gemm
+        skinny = self._skinny_weights() if t in (16, 32) else None
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -251,7 +268,9 @@ class Qwen3Encoder:
                 ops.rmsnorm(delta, L["ln1"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             # hipBLASLt picks a ~13 % faster kernel for this shape (K 2560, N 6144) at M = 32768 than at 65536
             # (scripts/probes/gemm_layouts.py), so large batches run the projection in row chunks
-            for lo in range(0, t, QKV_ROW_CHUNK):
+            if skinny is not None:
+                ops.skinny_gemm(normed, skinny[i]["qkv"], qkv, t, width)
+            for lo in range(0, t if skinny is None else 0, QKV_ROW_CHUNK):
                 hi = min(t, lo + QKV_ROW_CHUNK)
                 torch.matmul(normed[lo:hi], L["qkv"].t(), out=qkv[lo:hi])
             ops.qk_norm_rope(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
@@ -274,6 +293,14 @@ class Qwen3Encoder:
                 out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
                 ops.pool_normalize(resid_l, self.final_norm, batch.cu_one, out, c.out_dim, 0, c.rms_norm_eps, delta=delta_l)
                 return out
+            if skinny is not None:
+                delta = ops.skinny_gemm(attn, skinny[i]["o"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
+                                        c.hidden_size)
+                ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
+                ops.skinny_gemm(normed, skinny[i]["gate_up"], act, t, 2 * c.intermediate_size, swiglu=True)
+                delta = ops.skinny_gemm(act, skinny[i]["down"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
+                                        c.hidden_size)
+                continue
             delta = F.linear(attn, L["o"])
             ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             gate_up = F.linear(normed, L["gate_up"])
@@ -290,9 +317,77 @@ class Qwen3Encoder:
             raise ValueError(f"unknown pooling {c.pooling!r}")
         return out
 
+    # -- small batches: one hipGraph replay per forward ---------------------------------------------------
+    # A /retrieve request embeds ONE query (/root/reference/app/retrieve.py:427).  At 16 tokens the eager forward is
+    # ~470 kernel launches from Python (36 layers x 13) = 5 ms for 25 us of weight streaming per layer; captured
+    # once per shape it is one graph launch.  Shape = (sequences, bucket length): every sequence is padded BEHIND
+    # its last real token up to the bucket (causal attention: a real token never sees a later pad) and pooled at its
+    # real last token, whose position is DATA (a device tensor), not shape.
+    SMALL_BUCKETS = (16, 32, 64, 128, 256, 512, 1024)
+    SMALL_MAX_TOKENS = 2048      # padded tokens per forward that still take this path
+    SMALL_FREE_TOKENS = 128      # up to here the forward streams weights: padded tokens cost nothing
+    SMALL_MAX_WASTE = 1.25       # beyond it: at most this many padded tokens per real token
+    SMALL_MAX_GRAPHS = 12
+
+    def _small_bucket(self, lens: Sequence[int]) -> Optional[int]:
+        if (self.cfg.pooling != "last" or not lens or os.environ.get("CRAG_ENC_NO_GRAPH") is not None
+                or os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is not None):
+            return None
+        longest, real = max(lens), sum(lens)
+        for b in self.SMALL_BUCKETS:
+            if longest <= b:
+                padded = b * len(lens)
+                ok = padded <= self.SMALL_FREE_TOKENS or (padded <= self.SMALL_MAX_TOKENS and
+                                                          padded <= self.SMALL_MAX_WASTE * real)
+                return b if ok else None
+        return None
+
+    def _small_graph(self, n_seqs: int, bucket: int):
+        cache = self.__dict__.setdefault("_graphs", {})
+        key = (n_seqs, bucket)
+        hit = cache.get(key)
+        if hit is not None:
+            hit["used"] = self.__dict__["_graph_clock"] = self.__dict__.get("_graph_clock", 0) + 1
+            return hit
+        if len(cache) >= self.SMALL_MAX_GRAPHS:   # drop the least recently used graph (and its private pool)
+            del cache[min(cache, key=lambda k: cache[k]["used"])]
+        batch = PackedBatch.build([bucket] * n_seqs, self.device)
+        ids = torch.zeros(n_seqs * bucket, dtype=torch.int32, device=self.device)
+        batch.last_tok = torch.arange(1, n_seqs + 1, dtype=torch.int64, device=self.device) * bucket - 1
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):          # warm-up outside the capture (library handles, autotuning)
+            self.forward_packed(ids, batch)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward_packed(ids, batch)
+        entry = {"graph": graph, "ids": ids, "last_tok": batch.last_tok, "out": out, "batch": batch,
+                 "used": self.__dict__.get("_graph_clock", 0)}
+        cache[key] = entry
+        return entry
+
+    @torch.no_grad()
+    def _forward_small(self, token_lists: Sequence[Sequence[int]], lens: Sequence[int], bucket: int) -> torch.Tensor:
+        n = len(lens)
+        g = self._small_graph(n, bucket)
+        host = np.zeros((n, bucket), dtype=np.int32)
+        for i, (tl, m) in enumerate(zip(token_lists, lens)):
+            host[i, :m] = np.asarray(tl[:m], dtype=np.int32)
+        last = np.arange(n, dtype=np.int64) * bucket + (np.asarray(lens, dtype=np.int64) - 1)
+        g["ids"].copy_(torch.from_numpy(host.reshape(-1)), non_blocking=True)
+        g["last_tok"].copy_(torch.from_numpy(last), non_blocking=True)
+        g["graph"].replay()
+        return g["out"].clone()
+
     @torch.no_grad()
     def embed_token_lists(self, token_lists: Sequence[Sequence[int]]) -> torch.Tensor:
         lens = [min(len(tl), self.cfg.max_length) for tl in token_lists]
+        if any(n <= 0 for n in lens):
+            raise ValueError("every sequence needs at least one token")
+        bucket = self._small_bucket(lens)
+        if bucket is not None:
+            return self._forward_small(token_lists, lens, bucket)
         flat = np.concatenate([np.asarray(tl[:n], dtype=np.int32) for tl, n in zip(token_lists, lens)])
         batch = PackedBatch.build(lens, self.device)
         ids = torch.from_numpy(flat).to(self.device)

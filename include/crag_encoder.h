@@ -75,6 +75,19 @@ int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *d
                                 const int32_t *cu_seqlens, float *out, int n_seqs, int hidden, int out_dim,
                                 int mode, float eps, void *stream);
 
+/* Linear layer for m_rows <= 32 tokens -- ONE query per /retrieve request (retrieve.py:427) -- as a weight stream:
+ * out[m_rows, n] = x[m_rows, k] @ W[n, k]^T (bf16 in, fp32 accumulate, bf16 out).
+ *   x      [m_pad, k] bf16, m_pad = 16 or 32 rows allocated (rows >= m_rows are padding and never stored)
+ *   wsw    the weight in MFMA A-fragment order: [n/16][k/32][lane = 16 (kk/8) + row][8] = W[16 tile + row][32 step +
+ *          8 (lane >> 4) + e]  (torch: W.view(n/16, 16, k/32, 4, 8).permute(0, 2, 3, 1, 4).contiguous())
+ *   epilogue 0: out [m_rows, n].
+ *   epilogue 1 (gate|up projection): the rows of W are interleaved per 8 features -- tile t = gate rows 8t..8t+7,
+ *          then up rows 8t..8t+7 -- and out [m_rows, n/2] = silu(gate) * up with the model's bf16 roundings
+ *          (crag_enc_swiglu's arithmetic).
+ * Built for the Qwen3-Embedding-4B widths: k = 2560, 4096 (epilogue 0) or 9728 (epilogue 0); k = 2560 (epilogue 1). */
+int crag_enc_skinny_gemm(const uint16_t *x, const uint16_t *wsw, uint16_t *out, int m_rows, int m_pad, int n, int k,
+                         int epilogue, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ def run(rows: int, nq: int, k: int, steps: int = 200) -> None:
         c = torch.randn(m, 1024, generator=g, device=dev)
         index.add(c / c.norm(dim=1, keepdim=True))
     q = torch.randn(nq, 1024, generator=g, device=dev)
+    q = q / q.norm(dim=1, keepdim=True)
     oi = torch.empty(nq, k, dtype=torch.int64, device=dev)
     osc = torch.empty(nq, k, dtype=torch.float32, device=dev)
     oc = torch.empty(nq, dtype=torch.int32, device=dev)

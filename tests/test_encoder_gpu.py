@@ -279,6 +279,66 @@ def test_last_layer_on_pooled_rows_only_equals_the_full_last_layer(gpu, monkeypa
     assert ((short.cpu() * want).sum(-1)).min() > 0.9995
 
 
+@pytest.mark.parametrize("k,n,swiglu", [(2560, 6144, False), (4096, 2560, False), (9728, 2560, False), (2560, 19456, True)])
+@pytest.mark.parametrize("m_rows,m_pad", [(1, 16), (16, 16), (17, 32), (32, 32)])
+def test_skinny_gemm_streams_the_weights_for_one_short_query(gpu, k, n, swiglu, m_rows, m_pad):
+    """crag_enc_skinny_gemm (the projections of the encoder at 16 / 32 tokens, the reference's one-query-per-request
+    operating point) against torch: bf16 operands, fp32 accumulation; the SwiGLU form against crag_enc_swiglu's
+    arithmetic on the bf16-rounded reference projection.  Padding rows never reach the output."""
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(k + n + m_rows)
+    x = torch.randn(m_pad, k, generator=g).to(BF)
+    x[m_rows:] = float("nan")                                   # padding rows: anything, even NaN
+    w = (torch.randn(n, k, generator=g) * 0.02).to(BF)
+    xd, wd = x.to(DEV), w.to(DEV)
+    ref = x[:m_rows].float() @ w.float().t()                    # [m_rows, n] fp32
+    if not swiglu:
+        out = torch.full((m_rows + 1, n), 7.0, dtype=BF, device=DEV)
+        ops.skinny_gemm(xd, ops.skinny_weight(wd), out[:m_rows], m_rows, n)
+        got = out[:m_rows].float().cpu()
+        assert torch.all(out[m_rows] == 7.0)                    # nothing written behind the real rows
+        assert torch.allclose(got, ref, atol=2e-2, rtol=1.2e-2), (got - ref).abs().max()
+        assert (got - ref.to(BF).float()).abs().max() <= 2 * ref.abs().max() * 2 ** -8
+    else:
+        inter = n // 2
+        out = torch.full((m_rows + 1, inter), 7.0, dtype=BF, device=DEV)
+        ops.skinny_gemm(xd, ops.skinny_gate_up_weight(wd), out[:m_rows], m_rows, n, swiglu=True)
+        assert torch.all(out[m_rows] == 7.0)
+        want = torch.empty(m_rows, inter, dtype=BF, device=DEV)
+        ops.swiglu(ref.to(BF).to(DEV).contiguous(), want)
+        got, want = out[:m_rows].float().cpu(), want.float().cpu()
+        # gate / up sums may round to a neighbouring bf16 (another summation order): one bf16 ulp through silu * up
+        assert torch.allclose(got, want, atol=3e-3, rtol=3e-2), (got - want).abs().max()
+
+
+def test_small_batches_replay_one_graph_per_shape_and_match_the_eager_forward(gpu, monkeypatch):
+    """A /retrieve request embeds one short query: embed_token_lists pads every sequence behind its last real token
+    to a bucket length and replays a captured graph per (sequences, bucket).  Same embeddings as the eager packed
+    forward (up to the GEMM tiling the library picks for another M) and as transformers; the pads behind the pooled
+    token change nothing; a graph is reused for other lengths of its bucket."""
+    model, enc, cfg = _tiny_hf_and_mine("last")
+    rng = np.random.default_rng(23)
+    cases = [[5], [32], [33], [1], [17, 3, 32, 9], [64, 60, 40], [210], [16] * 8]
+    for lens in cases:
+        token_lists = [rng.integers(0, 503, size=n).tolist() for n in lens]
+        monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
+        fast = enc.embed_token_lists(token_lists)
+        again = enc.embed_token_lists(token_lists)
+        assert torch.equal(fast, again)                         # a replay is deterministic
+        monkeypatch.setenv("CRAG_ENC_NO_GRAPH", "1")
+        eager = enc.embed_token_lists(token_lists)
+        monkeypatch.delenv("CRAG_ENC_NO_GRAPH")
+        want = _hf_embed(model, cfg, token_lists, "last")
+        assert ((fast * eager).sum(-1)).min() > 0.99999 and (fast - eager).abs().max() < 2e-3, lens
+        assert ((fast.cpu() * want).sum(-1)).min() > 0.9995, lens
+    keys = sorted(enc._graphs)
+    assert keys == [(1, 16), (1, 32), (1, 64), (1, 256), (3, 64), (4, 32), (8, 16)], keys
+    # beyond the token budget of the graph path the eager packed forward runs (no new graph)
+    big = [rng.integers(0, 503, size=600).tolist() for _ in range(5)]
+    enc.embed_token_lists(big)
+    assert sorted(enc._graphs) == keys
+
+
 def test_packed_batch_equals_one_by_one_and_encoder_protocol(gpu, monkeypatch):
     from cadence_rag_amd import embeddings
     from cadence_rag_amd.config import settings

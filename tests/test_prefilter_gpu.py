@@ -232,3 +232,39 @@ def test_rows_with_extreme_norms_keep_the_index_on_the_fp32_scan(gpu, monkeypatc
         assert_topk_matches(*got, *want, tol=TOL)
     finally:
         ix.close()
+
+
+
+def test_workspace_state_is_left_clean_by_every_kind_of_search(gpu, monkeypatch):
+    """The selection kernel zeroes its query's candidate count and class maxima when it is done with them, and the
+    overflow word carries the sequence number of the search that overflowed (no kernel resets it).  A sequence of
+    searches of different batch sizes on ONE workspace — plain, overflowing (answered by the fallback blocks of the
+    selection launch), masked — must each give what a fresh index gives."""
+    rng = np.random.default_rng(2024)
+    n = 50_000
+    corpus = unit_rows(rng, n)
+    corpus[5_000:25_000] = corpus[3]                       # 20 000 duplicates: a query near row 3 overflows its list
+    q_big = rng.standard_normal((64, 1024)).astype(np.float32)
+    q_big -= np.outer(q_big @ corpus[3], corpus[3])        # these never near the duplicates
+    q_over = np.concatenate([corpus[3][None] * 1.5, q_big[:6]])
+    mask = rng.random(n) < 0.3
+    packed = DenseIndex.pack_mask(mask)
+    plan = [(q_big, None), (q_over, None), (q_big[:7], None), (q_over, packed), (q_big, packed), (q_big[:33], None),
+            (q_over, None), (q_big, None)]
+    ix = _index(corpus, monkeypatch)
+    try:
+        got = [ix.search(q, 10, row_mask=m) for q, m in plan]
+    finally:
+        ix.close()
+    for (q, m), res in zip(plan, got):
+        fresh = _index(corpus, monkeypatch)
+        try:
+            want = fresh.search(q, 10, row_mask=m)
+        finally:
+            fresh.close()
+        for a, b in zip(res, want):
+            assert np.array_equal(a, b, equal_nan=True)
+    assert got[1][0][0].tolist() == [3] + list(range(5_000, 5_009))
+    m8 = np.packbits(mask, bitorder="little")
+    want = oracle.exact_topk(q_over[:2], corpus, 10, mask=m8, mode=oracle.F64, fast=True)
+    assert_topk_matches(got[3][0][:2], got[3][1][:2], got[3][2][:2], *want, tol=TOL)
