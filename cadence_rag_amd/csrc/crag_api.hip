@@ -97,7 +97,7 @@ struct crag_index {
         bool in_use = false;
         DevBuf partial, gbound;
         // prepared queries (fragment order) and the prefilter path's per-query state
-        DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags;
+        DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags, pf_xkeys, pf_xids, pf_xcount, pf_xticket;
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
         uint32_t seq = 0;            // sequence number of the last prefilter search on this workspace (never 0 in use)
         bool done_recorded = false;  // ... once a second stream has appeared (single-stream callers pay no event)
@@ -107,7 +107,7 @@ struct crag_index {
     bool multi_stream = false;  // more than one stream has searched this index
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
-    bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false;
+    bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false, env_no_rsplit = false;
     int env_pf_nt = -1;                       // CRAG_PF_NT=0/1 forces the cache policy of the prefilter scan (developer switch)
     int64_t nt_above_bytes = 1536ll << 20;     // mirror bytes above which its loads stream (measured: no gain below ~1 GB)
     // a stored row whose norm lies outside [1e-30, 1e30]: the fp16 prefilter's error bound assumes normalised
@@ -348,6 +348,27 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fin.cap = cap;
         fin.merge = mp;
         fin.nq = nq;
+        // large k: several selection blocks per query share the exact rescoring (see finalize_fb_kernel)
+        fin.rsplit = (k <= 32 || ix->env_no_rsplit) ? 1 : (nq <= 16 ? 8 : (nq <= 128 ? 4 : 1));
+        fin.xkeys = nullptr;
+        fin.xids = nullptr;
+        fin.xcount = nullptr;
+        fin.xticket = nullptr;
+        if (fin.rsplit > 1) {
+            const size_t slots = (size_t)nq_pad * 8;
+            if ((rc = ws->pf_xkeys.ensure(slots * CRAG_MAX_K * sizeof(uint64_t)))) return rc;
+            if ((rc = ws->pf_xids.ensure(slots * CRAG_MAX_K * sizeof(int64_t)))) return rc;
+            if ((rc = ws->pf_xcount.ensure(slots * sizeof(uint2)))) return rc;
+            const size_t tneed = (size_t)nq_pad * sizeof(uint32_t);
+            if (tneed > ws->pf_xticket.bytes) {
+                if ((rc = ws->pf_xticket.ensure(tneed))) return rc;
+                HIP_TRY(hipMemsetAsync(ws->pf_xticket.p, 0, ws->pf_xticket.bytes, st));
+            }
+            fin.xkeys = (uint64_t *)ws->pf_xkeys.p;
+            fin.xids = (int64_t *)ws->pf_xids.p;
+            fin.xcount = (uint2 *)ws->pf_xcount.p;
+            fin.xticket = (uint32_t *)ws->pf_xticket.p;
+        }
         // the fallback of a search whose candidate list overflows: the self-contained generic scan (32 queries per
         // pass) inside the same launch, see finalize_fb_kernel
         sp.wide = 0;
@@ -458,6 +479,7 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_reverse = getenv("CRAG_NO_REVERSE") != nullptr;
     ix->env_unpipelined = getenv("CRAG_UNPIPELINED") != nullptr;
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
+    ix->env_no_rsplit = getenv("CRAG_NO_RSPLIT") != nullptr;  // developer switch: one selection block per query for any k
     if (const char *v = getenv("CRAG_PF_NT")) ix->env_pf_nt = atoi(v) ? 1 : 0;
     if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
@@ -511,6 +533,10 @@ int crag_index_destroy(crag_index *ix) {
         w.pf_cand.release();
         w.pf_count.release();
         w.pf_flags.release();
+        w.pf_xkeys.release();
+        w.pf_xids.release();
+        w.pf_xcount.release();
+        w.pf_xticket.release();
         if (w.done) (void)hipEventDestroy(w.done);
     }
     ix->stage_q.release();

@@ -964,18 +964,37 @@ int crag_enc_skinny_gemm(const uint16_t *x, const uint16_t *wsw, uint16_t *out, 
     hipLaunchKernelGGL((skinny_gemm_kernel<MG_, NT_, KS_, WAVES_, EPI_>), dim3((unsigned)(tiles / NT_)),      \
                        dim3(WAVES_ * 64), 0, st, p)
     const int mg = m_pad / 16;
+    // n-tiles per workgroup: every workgroup reads the activations of its K range once per NT tiles (x : W bytes =
+    // m_pad : 16 NT through the same L1 path), but tiles / NT workgroups must still cover the chip
+    int nt = epilogue ? 2 : 1;
+    if (const char *v = getenv("CRAG_SKINNY_NT")) nt = atoi(v);  // developer switch
+    if (nt < 1 || tiles % nt) return efail("skinny_gemm: %d n-tiles cannot be split %d ways", tiles, nt);
+#define CRAG_SKINNY_NT(MG_, KS_, WAVES_, EPI_)                              \
+    do {                                                                     \
+        if (nt == 1) CRAG_SKINNY(MG_, 1, KS_, WAVES_, EPI_);                 \
+        else if (nt == 2) CRAG_SKINNY(MG_, 2, KS_, WAVES_, EPI_);            \
+        else if (nt == 4) CRAG_SKINNY(MG_, 4, KS_, WAVES_, EPI_);            \
+        else return efail("skinny_gemm: n-tiles per workgroup must be 1, 2 or 4"); \
+    } while (0)
     if (k == 2560 && epilogue == 0) {
-        if (mg == 1) CRAG_SKINNY(1, 1, 10, 8, 0); else CRAG_SKINNY(2, 1, 10, 8, 0);
+        if (mg == 1) CRAG_SKINNY_NT(1, 10, 8, 0); else CRAG_SKINNY_NT(2, 10, 8, 0);
     } else if (k == 2560 && epilogue == 1) {
-        if (tiles & 1) return efail("skinny_gemm: the SwiGLU form needs an even number of n-tiles");
-        if (mg == 1) CRAG_SKINNY(1, 2, 10, 8, 1); else CRAG_SKINNY(2, 2, 10, 8, 1);
+        if (nt == 1) nt = 2;
+        if (mg == 1) CRAG_SKINNY_NT(1, 10, 8, 1); else CRAG_SKINNY_NT(2, 10, 8, 1);
     } else if (k == 4096 && epilogue == 0) {
-        if (mg == 1) CRAG_SKINNY(1, 1, 16, 8, 0); else CRAG_SKINNY(2, 1, 16, 8, 0);
+        if (getenv("CRAG_SKINNY_W16")) {  // developer switch: 16 waves per workgroup (more loads in flight per CU)
+            if (mg == 1) CRAG_SKINNY_NT(1, 8, 16, 0); else CRAG_SKINNY_NT(2, 8, 16, 0);
+        } else {
+            if (mg == 1) CRAG_SKINNY_NT(1, 16, 8, 0); else CRAG_SKINNY_NT(2, 16, 8, 0);
+        }
     } else if (k == 9728 && epilogue == 0) {
-        if (mg == 1) CRAG_SKINNY(1, 1, 38, 8, 0); else CRAG_SKINNY(2, 1, 19, 16, 0);
+        if (mg == 1 && getenv("CRAG_SKINNY_W16")) CRAG_SKINNY_NT(1, 19, 16, 0);
+        else if (mg == 1) CRAG_SKINNY_NT(1, 38, 8, 0);
+        else CRAG_SKINNY_NT(2, 19, 16, 0);
     } else {
         return efail("skinny_gemm: unsupported shape k=%d epilogue=%d (built for the Qwen3-Embedding-4B widths: k = 2560 / 4096 / 9728)", k, epilogue);
     }
+#undef CRAG_SKINNY_NT
 #undef CRAG_SKINNY
     return hip_ok("skinny_gemm");
 }

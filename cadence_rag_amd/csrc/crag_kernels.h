@@ -101,7 +101,12 @@ struct FinParams {
     int32_t *out_counts;
     unsigned long long *stats;  // nullable; PF_STAT_SLOTS records {candidates, rescored rows, searches}, record q % SLOTS
     int k, cap;
-    int nq;                     // selection blocks of the launch: [0, nq)
+    int nq;                     // selection blocks of the launch: [0, nq * rsplit)
+    int rsplit;                 // selection blocks per query (R)
+    uint64_t *xkeys;            // R > 1: [nq][R][k] exact keys of each block's own top-k
+    int64_t *xids;              //        [nq][R][k] their external ids
+    uint2 *xcount;              //        [nq][R] {keys written, rows rescored}
+    uint32_t *xticket;          //        [nq] arrival tickets, zero between searches
     // fallback role (flags[0] != 0: a candidate list overflowed): fb_blocks = scan.G * ceil(nq / 32) workgroups behind
     // the selection blocks run the exact fp32 scan, the one that finishes last merges
     int fb_blocks;

@@ -1586,10 +1586,18 @@ __global__ void fill_ids_kernel(int64_t *ids, int64_t pos, int64_t n, int64_t fi
 // valid bound.  Stale reads only prune less.
 constexpr float PF_DELTA = 1.25e-3f;
 // |approx - cos| <= sum_i |q_i c_i| (2u + u^2) [u = 2^-11, fp16 round-to-nearest of both operands, each in
-// [-1, 1] after normalisation]  <= 9.8e-4 by Cauchy-Schwarz, + fp16 subnormal flushes 2 * 32 * 2^-25 = 1.9e-6,
-// + fp32 accumulation of 1024 exact products and 7 partial sums, <= 1031 * 2^-23 = 1.23e-4 even if every add
-// truncates, + the fp32 normalisations 4 * 2^-24; sum 1.105e-3 (the difference between the fp32 chain and the
-// real-number cosine, < 2e-6, included).  tests/test_prefilter_gpu.py measures the actual worst case.
+// [-1, 1] after normalisation]  <= 9.8e-4 by Cauchy-Schwarz, + GRADUAL UNDERFLOW of components below 2^-14 (absolute
+// rounding error <= 2^-25 per element: 2 * 32 * 2^-25 = 1.9e-6), + fp32 accumulation of 1024 exact products and
+// 7 partial sums, <= 1031 * 2^-23 = 1.23e-4 even if every add truncates, + the fp32 normalisations 4 * 2^-24; sum
+// 1.105e-3 (the difference between the fp32 chain and the real-number cosine, < 2e-6, included).
+// The underflow term is a HARDWARE assumption: v_cvt_pk_f16_f32 (mirror, query fragments) and
+// v_mfma_f32_32x32x16_f16 must keep fp16 subnormals -- flushed to zero they would cost up to
+// ||small part|| * ||q|| <= 32 * 2^-14 = 1.95e-3 > delta.  tests/test_subnormal_bound.py builds exactly that case
+// (unit vectors whose mass sits in [0.85, 0.98] * 2^-14, on the row side and on the query side, planted around the
+// k-th score so that a flushing implementation provably loses them -- the CPU half of the test shows it on a model
+// of the rule) and the kernels pass it on MI355X / ROCm 7.2: subnormals are kept (ISA 7.4: MFMA never flushes C/D,
+// A/B follow MODE.denorm, which hipcc leaves at "keep" for f16).  tests/test_prefilter_gpu.py measures the
+// actual worst case on ordinary inputs.
 constexpr int PF_FLUSH_ABOVE = 768;                // staged candidates that trigger a flush at the next tile boundary
 constexpr int PF_STAGE = PF_FLUSH_ABOVE + 2048;    // per-workgroup staging entries in LDS: a tile adds at most 32 x 64
 
@@ -2122,8 +2130,12 @@ union FinFbLds {
 };
 
 // ONE launch behind the prefilter scan, two kinds of workgroups (512 threads each):
-//  * blocks [0, nq): selection.  Waves 0-3 do the work described above, waves 4-7 end at once.
-//  * blocks [nq, nq + fb_blocks): the FALLBACK for a search whose candidate list overflowed (thousands of rows within
+//  * blocks [0, nq * R): selection, R blocks per query.  Waves 0-3 do the work described above, waves 4-7 end at
+//    once.  R = 1 for k <= 32.  Larger k (the reference's own dense k is 50, the hybrid lane's 100): every block of a
+//    query repeats the cheap part (k-th approximate score among the candidates), rescores the survivors whose list
+//    position is r mod R exactly (131 rows x 4 KiB per query at k = 100: 30 us for one workgroup), writes its own
+//    top-k to scratch, and the block that arrives LAST at the query's ticket gathers and ranks the R lists.
+//  * blocks [nq * R, nq * R + fb_blocks): the FALLBACK for a search whose candidate list overflowed (thousands of rows within
 //    2 delta of the k-th best: boilerplate chunks embed identically).  They end at once unless the overflow flag is
 //    set; then each runs the exact fp32 scan of its row range (scan_body: self-contained, it normalises the raw
 //    queries itself), and the workgroup that finishes LAST merges the partial lists of every query -- no workgroup
@@ -2138,9 +2150,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     __shared__ FinFbLds U;
     __shared__ int s_last;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if ((int)blockIdx.x >= p.nq) {
+    const int R = p.rsplit;  // selection blocks per query (1, or 4 / 8 for large k: the exact rescoring is shared)
+    if ((int)blockIdx.x >= p.nq * R) {
         if (__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq) return;
-        const int b = (int)blockIdx.x - p.nq;
+        const int b = (int)blockIdx.x - p.nq * R;
         scan_body<S>(p.scan, b % p.scan.G, b / p.scan.G, U.slab);
         // every wave's list stores are drained at the barrier; one lane releases them and draws a ticket
         __syncthreads();
@@ -2172,7 +2185,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     auto &hist = U.f.hist;
     int &s_nbest = U.f.s_nbest, &s_nsurv = U.f.s_nsurv, &s_rescored = U.f.s_rescored;
     uint32_t &s_kth = U.f.s_kth;
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int q = (int)blockIdx.x / R, rpart = (int)blockIdx.x % R, tid = threadIdx.x;
     // Everything the kernel needs first, in flight together (one memory round trip instead of a chain of four:
     // flag -> count -> candidates -> ...): the overflow flag, the candidate count, the first MERGE_THREADS
     // candidates (read before the count is known -- the list has `cap` >= MERGE_THREADS slots; the usual few dozen
@@ -2190,16 +2203,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     // than PF_STAT_SLOTS queries, or on several streams at once, may lose counts; results never depend on them.
     unsigned long long *const stat = p.stats ? p.stats + (size_t)(q % PF_STAT_SLOTS) * 3 : nullptr;
     unsigned long long stat_old[3] = {0ull, 0ull, 0ull};
-    if (stat && tid == 0) {
+    if (stat && tid == 0 && R == 1) {
         stat_old[0] = stat[0];
         stat_old[1] = stat[1];
         stat_old[2] = stat[2];
     }
     // the scan is over: leave the query's state zeroed for the next search on this workspace (the count only once
-    // every thread has its copy: behind the first barrier below)
-    if (tid < PF_BOUND_CELLS) p.gbound[(size_t)q * PF_BOUND_CELLS + tid] = 0u;
+    // every thread of every block of the query has its copy: behind the first barrier below, or by the block that
+    // finishes last when the query has several)
+    if (tid < PF_BOUND_CELLS && rpart == 0) p.gbound[(size_t)q * PF_BOUND_CELLS + tid] = 0u;
     if (overflow) {  // (uniform over the grid) the fallback blocks of this launch answer this search
-        if (tid == 0) p.count[q] = 0u;
+        if (tid == 0 && rpart == 0) p.count[q] = 0u;   // (the other blocks of the query use their copy for nothing)
         return;
     }
     const int k = p.k;
@@ -2215,7 +2229,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         s_kth = 0u;
     }
     __syncthreads();
-    if (tid == 0) p.count[q] = 0u;
+    if (tid == 0 && R == 1) p.count[q] = 0u;
 
     // 1. k-th largest approximate score among the candidates
     uint32_t thr_ord = 0u;
@@ -2336,7 +2350,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         __syncthreads();
         for (int e = tid; e < rn; e += MERGE_THREADS) {
             const uint2 ce = in_lds ? lcand[e] : gcand[r0 + e];
-            if (ce.x >= thr_ord) surv[atomicAdd(&s_nsurv, 1)] = ce.y;
+            // (several blocks per query: block r rescores the candidates whose list position is r mod R)
+            if (ce.x >= thr_ord && (((r0 + e) & (R - 1)) == rpart)) surv[atomicAdd(&s_nsurv, 1)] = ce.y;
         }
         __syncthreads();
         const int ns = s_nsurv;
@@ -2399,7 +2414,61 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     }
 
     // 3. rank by counting among the exact keys
-    const int B = s_nbest;
+    int B = s_nbest;
+    unsigned long long rescored_all = (unsigned long long)s_rescored;
+    if (R > 1) {
+        // this block's own top-k (no other key of its share can be in the query's top-k) -> global scratch; the block
+        // of the query that finishes LAST gathers the R lists and ranks them.  Nobody waits for anybody.
+        uint64_t *const xk = p.xkeys + ((size_t)q * R + rpart) * k;
+        int64_t *const xi = p.xids + ((size_t)q * R + rpart) * k;
+        for (int e = tid; e < B; e += MERGE_THREADS) {
+            const uint64_t mine = best[e];
+            int rank = 0;
+            for (int i = 0; i < B; ++i) rank += (best[i] > mine) ? 1 : 0;
+            if (rank < k) {
+                xk[rank] = mine;
+                xi[rank] = best_id[e];
+            }
+        }
+        if (tid == 0) p.xcount[(size_t)q * R + rpart] = make_uint2((uint32_t)(B < k ? B : k), (uint32_t)s_rescored);
+        __syncthreads();  // (drains every wave's stores)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t t = __hip_atomic_fetch_add(p.xticket + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (t == (uint32_t)(R - 1)) ? 1 : 0;
+            if (s_last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        if (!s_last) return;
+        int base = 0;
+        rescored_all = 0ull;
+        for (int rr = 0; rr < R; ++rr) {  // (R <= 8 lists of <= k keys each: <= 1024 keys)
+            const uint2 cr = p.xcount[(size_t)q * R + rr];
+            const uint64_t *sk = p.xkeys + ((size_t)q * R + rr) * k;
+            const int64_t *si = p.xids + ((size_t)q * R + rr) * k;
+            for (int e = tid; e < (int)cr.x; e += MERGE_THREADS) {
+                best[base + e] = sk[e];
+                best_id[base + e] = si[e];
+            }
+            base += (int)cr.x;
+            rescored_all += cr.y;
+        }
+        B = base;
+        if (tid == 0) {
+            __hip_atomic_store(p.xticket + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.count[q] = 0u;
+            if (stat) {
+                stat_old[0] = stat[0];
+                stat_old[1] = stat[1];
+                stat_old[2] = stat[2];
+            }
+        }
+        __syncthreads();
+    }
     const int count = B < k ? B : k;
     for (int e = tid; e < B; e += MERGE_THREADS) {
         const uint64_t mine = best[e];
@@ -2418,7 +2487,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         p.out_counts[q] = count;
         if (stat) {
             stat[0] = stat_old[0] + (unsigned long long)total;
-            stat[1] = stat_old[1] + (unsigned long long)s_rescored;
+            stat[1] = stat_old[1] + rescored_all;
             if (q == 0) stat[2] = stat_old[2] + 1ull;
         }
     }
@@ -2505,7 +2574,7 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
 }
 
 hipError_t launch_finalize(const FinParams &p, hipStream_t st) {
-    const dim3 grid(p.nq + p.fb_blocks), block(SCAN_THREADS);
+    const dim3 grid(p.nq * p.rsplit + p.fb_blocks), block(SCAN_THREADS);
     const int ks = (p.k + 31) / 32;  // list slots of the fallback scan
     if (ks == 1) hipLaunchKernelGGL(finalize_fb_kernel<1>, grid, block, 0, st, p);
     else if (ks == 2) hipLaunchKernelGGL(finalize_fb_kernel<2>, grid, block, 0, st, p);

@@ -4,10 +4,15 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RN=${ROUND:-r02}
+RN=${ROUND:-r03}
 O=$R/gpurun_out/$RN
 mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
+# the driver's own invocation (few steps between synchronisations)
+python bench.py --steps 20 --warmup 5 --no-encode --no-target-1m --no-fp32-rows-leg --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
+# two ranks folded onto the one GPU of this box over gloo: the N > 1 code path (shards, exchange, merge, per-rank
+# breakdown) end to end; its times say nothing about xGMI
+CRAG_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 100 --warmup 10 --rounds 2 --no-encode --no-cpu-baseline > $O/bench_n2_gloo_rehearsal.json 2> $O/bench_n2.err || true
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
 # the headline leg alone (in the full command above the 1M legs launch the same kernel template)
@@ -33,5 +38,6 @@ python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m32.csv $O/${RN}_
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m64.csv $O/${RN}_pmc_WRITE_SIZE_1m64.csv 1000000x64x10 $O/traffic.json
 # raw traces are large: keep only summaries
 rm -rf $O/pmc_* $O/stats $O/stats_headline
+cp $O/bench.json $O/${RN}_bench_line.json; cp $O/bench_steps20.json $O/${RN}_bench_line_steps20.json; grep '^{' $O/bench_n2_gloo_rehearsal.json > $O/${RN}_bench_n2_gloo_rehearsal.json || true
 cat $O/traffic.json
 head -14 $O/${RN}_bench_kernel_stats.csv | cut -c1-160

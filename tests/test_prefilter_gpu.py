@@ -268,3 +268,40 @@ def test_workspace_state_is_left_clean_by_every_kind_of_search(gpu, monkeypatch)
     m8 = np.packbits(mask, bitorder="little")
     want = oracle.exact_topk(q_over[:2], corpus, 10, mask=m8, mode=oracle.F64, fast=True)
     assert_topk_matches(got[3][0][:2], got[3][1][:2], got[3][2][:2], *want, tol=TOL)
+
+
+@pytest.mark.parametrize("n,nq,k", [(40_000, 1, 50), (60_000, 64, 100), (45_000, 7, 128), (50_000, 16, 33), (40_000, 130, 64)])
+def test_selection_shared_by_several_blocks_per_query_equals_one_block(gpu, monkeypatch, n, nq, k):
+    """k > 32: R = 4 or 8 selection blocks per query share the exact rescoring and the block that arrives last ranks
+    their lists (CRAG_NO_RSPLIT=1: one block per query, round 2's form).  Same results bit for bit, the same rows
+    rescored, also with a per-query mask and on repeated searches (the tickets are left at zero)."""
+    rng = np.random.default_rng(n + nq + k)
+    corpus = unit_rows(rng, n) * rng.uniform(0.1, 5.0, (n, 1)).astype(np.float32)
+    q = rng.standard_normal((nq, 1024)).astype(np.float32)
+    elig = rng.random((nq, n)) < 0.4
+    packed = DenseIndex.pack_mask(elig)
+    out = {}
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv("CRAG_NO_RSPLIT", raising=False)
+        else:
+            monkeypatch.setenv("CRAG_NO_RSPLIT", "1")
+        ix = _index(corpus, monkeypatch)
+        try:
+            ix.prefilter_stats()
+            res = [ix.search(q, k), ix.search(q, k), ix.search(q, k, row_mask=packed), ix.search(q[: max(1, nq // 2)], k)]
+            out[split] = (res, ix.prefilter_stats())
+        finally:
+            ix.close()
+    monkeypatch.delenv("CRAG_NO_RSPLIT", raising=False)
+    for a, b in zip(out[True][0], out[False][0]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+    # the same searches took the selection path and the same rows were rescored (the number of CANDIDATES depends on when
+    # the scan's workgroups saw each other's bounds: it varies from run to run, the survivors do not)
+    assert out[True][1]["searches"] == out[False][1]["searches"] == 4
+    assert out[True][1]["rescored_rows"] == out[False][1]["rescored_rows"]
+    s = min(nq, 3)
+    want = oracle.exact_topk(q[:s], corpus, k, mode=oracle.F64, fast=True)
+    got = out[True][0][0]
+    assert_topk_matches(got[0][:s], got[1][:s], got[2][:s], *want, tol=TOL)
