@@ -100,9 +100,16 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
             fence_extra()
         torch.cuda.synchronize()
 
-    t_end = time.perf_counter() + prewarm_s  # clocks ramp over ~0.1 s; untimed
-    while time.perf_counter() < t_end:
-        for _ in range(16):
+    if step_extra is None:
+        t_end = time.perf_counter() + prewarm_s  # clocks ramp over ~0.1 s; untimed
+        while time.perf_counter() < t_end:
+            for _ in range(16):
+                step()
+            torch.cuda.synchronize()
+    else:
+        # N > 1: a step contains a collective, so every rank must run the SAME number of steps -- a clock-bounded
+        # loop lets one rank issue 16 all-gathers more than its peers and the job hangs at its end
+        for _ in range(int(200 * prewarm_s / 0.3) + 16):
             step()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -535,11 +542,11 @@ def query_path_leg(enc, cfg, big_index, big, dev, dev_index, query_tokens: int =
             def encode():   # the product path from token ids on: host packing, H2D, forward (one graph replay)
                 return enc.embed_token_lists(token_lists)
 
-            os.environ["CRAG_ENC_NO_GRAPH"] = "1"      # the eager forward (round 2's only path), for comparison
-            try:
+            os.environ["CRAG_ENC_NO_GRAPH"] = os.environ["CRAG_ENC_NO_SKINNY"] = "1"   # round 2's only path: eager
+            try:                                                                       # launches, library GEMMs
                 eager_lat = lat(encode, 8)
             finally:
-                del os.environ["CRAG_ENC_NO_GRAPH"]
+                del os.environ["CRAG_ENC_NO_GRAPH"], os.environ["CRAG_ENC_NO_SKINNY"]
             qv = encode()
 
             def request():

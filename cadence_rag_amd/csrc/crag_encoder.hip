@@ -25,6 +25,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 int efail(const char *fmt, ...) {
     char buf[384];
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(const u16 *x, con
 // 16 lanes per head vector (8 elements each); lane j of the group pairs with lane j^8 for
 // rotate_half (element i <-> i + 64)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16 *qkv, const u16 *qw, const u16 *kw,
-                                                           const float *cos_sin, const int32_t *positions,
-                                                           int64_t n_tokens, int hq, int hkv, float eps) {
+__device__ __forceinline__ void qk_norm_rope_body(u16 *qkv, const u16 *qw, const u16 *kw, const float *cos_sin,
+                                                  const int32_t *positions, int64_t n_tokens, int hq, int hkv,
+                                                  float eps, int64_t first_token, int64_t token_stride) {
     // One block trip = one token: group g (16 lanes) walks the head vectors g, g + 16, g + 32, ... of the token with
     // the token's cos/sin chunk and the norm weights in registers (loaded per head vector they were 64 B of table
     // reads per 16 B of q/k: twice the data traffic, from the caches).
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16 *qkv, const u16 *
     const bool first_half = sub < 8;   // elements [0, 64): out = x*cos - x[i+64]*sin ; else x*cos + x[i-64]*sin
     const Pack8 wq8 = *reinterpret_cast<const Pack8 *>(qw + sub * 8);
     const Pack8 wk8 = *reinterpret_cast<const Pack8 *>(kw + sub * 8);
-    for (int64_t t = blockIdx.x; t < n_tokens; t += gridDim.x) {
+    for (int64_t t = first_token; t < n_tokens; t += token_stride) {
         const int pos = positions[t];
         const float *cs = cos_sin + ((int64_t)pos * 64 + (sub & 7) * 8) * 2;
         float c[8], sn[8];
@@ -194,14 +195,20 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16 *qkv, const u16 *
     }
 }
 
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(u16 *qkv, const u16 *qw, const u16 *kw,
+                                                           const float *cos_sin, const int32_t *positions,
+                                                           int64_t n_tokens, int hq, int hkv, float eps) {
+    qk_norm_rope_body(qkv, qw, kw, cos_sin, positions, n_tokens, hq, hkv, eps, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // V transpose: qkv[T, ..] V part -> Vt[hkv][128][t_pad]; one block per (32 padded slots, kv head)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void v_transpose_kernel(const u16 *qkv, u16 *vt, const int32_t *tok_of_pad,
-                                                          int64_t t_pad, int hq, int hkv) {
-    __shared__ u16 tile[32][CRAG_HEAD_DIM + 8];
-    const int64_t p0 = (int64_t)blockIdx.x * 32;
-    const int kvh = blockIdx.y;
+__device__ __forceinline__ void v_transpose_body(const u16 *qkv, u16 *vt, const int32_t *tok_of_pad, int64_t t_pad,
+                                                 int hq, int hkv, int slot_block, int kvh_,
+                                                 u16 (*tile)[CRAG_HEAD_DIM + 8]) {
+    const int64_t p0 = (int64_t)slot_block * 32;
+    const int kvh = kvh_;
     const int64_t row_stride = (int64_t)(hq + 2 * hkv) * CRAG_HEAD_DIM;
     {
         const int slot = threadIdx.x >> 3, c8 = threadIdx.x & 7;  // 32 slots x 8 chunks of 16 elements
@@ -235,6 +242,28 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const u16 *qkv, u16 *v
         }
         reinterpret_cast<Pack8 *>(dst)[0] = o0;
         reinterpret_cast<Pack8 *>(dst)[1] = o1;
+    }
+}
+
+__global__ __launch_bounds__(256) void v_transpose_kernel(const u16 *qkv, u16 *vt, const int32_t *tok_of_pad,
+                                                          int64_t t_pad, int hq, int hkv) {
+    __shared__ u16 tile[32][CRAG_HEAD_DIM + 8];
+    v_transpose_body(qkv, vt, tok_of_pad, t_pad, hq, hkv, blockIdx.x, blockIdx.y, tile);
+}
+
+// Both in ONE launch (they touch disjoint columns of the fused qkv rows: q|k in place, v -> V^T): blocks
+// [0, rope_blocks) walk the tokens, the rest are the (slot block, kv head) tiles of the transpose.  At 16 tokens a
+// decoder layer is eight launches of a few microseconds each; every boundary removed is ~4 us of 80.
+__global__ __launch_bounds__(256) void qk_rope_vt_kernel(u16 *qkv, const u16 *qw, const u16 *kw, const float *cos_sin,
+                                                         const int32_t *positions, int64_t n_tokens, int hq, int hkv,
+                                                         float eps, u16 *vt, const int32_t *tok_of_pad, int64_t t_pad,
+                                                         int rope_blocks) {
+    __shared__ u16 tile[32][CRAG_HEAD_DIM + 8];
+    if ((int)blockIdx.x < rope_blocks) {
+        qk_norm_rope_body(qkv, qw, kw, cos_sin, positions, n_tokens, hq, hkv, eps, blockIdx.x, rope_blocks);
+    } else {
+        const int b = (int)blockIdx.x - rope_blocks;
+        v_transpose_body(qkv, vt, tok_of_pad, t_pad, hq, hkv, b / hkv, b % hkv, tile);
     }
 }
 
@@ -751,8 +780,6 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, cons
 //     interleaved that way), and the epilogue writes silu(gate) * up with the model's bf16 roundings (gate and up
 //     rounded to bf16 as a linear layer's output would be, silu in fp32 rounded to bf16, product rounded to bf16).
 // ---------------------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-
 struct SkinnyParams {
     const u16 *x;    // [16 * MG, K] bf16, rows >= m_rows are padding (never stored)
     const u16 *wsw;  // fragment-ordered weights
@@ -766,16 +793,17 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(SkinnyParams p)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ksteps = p.k >> 5;
-    // activations: B[k = 8 (lane >> 4) + j][col = lane & 15] = x[token 16 mg + (lane & 15)][32 (w KS + s) + 8 (lane >> 4) + j]
+    const int kw0 = w * KS;  // first k-step of this wave
+    // activations: B[k = 8 (lane >> 4) + j][col = lane & 15] = x[token 16 mg + (lane & 15)][32 (kw0 + s) + 8 (lane >> 4) + j]
     bf16x8 xb[MG][KS];
 #pragma unroll
     for (int mg = 0; mg < MG; ++mg) {
-        const u16 *xr = p.x + (size_t)(16 * mg + (lane & 15)) * p.k + (size_t)w * KS * 32 + 8 * (lane >> 4);
+        const u16 *xr = p.x + (size_t)(16 * mg + (lane & 15)) * p.k + (size_t)kw0 * 32 + 8 * (lane >> 4);
 #pragma unroll
         for (int s = 0; s < KS; ++s) xb[mg][s] = *reinterpret_cast<const bf16x8 *>(xr + 32 * s);
     }
     constexpr int TOT = NT * KS, D = TOT < 12 ? TOT : 12;
-    const u16 *wbase = p.wsw + ((size_t)blockIdx.x * NT * ksteps + (size_t)w * KS) * 512 + lane * 8;
+    const u16 *wbase = p.wsw + ((size_t)blockIdx.x * NT * ksteps + (size_t)kw0) * 512 + lane * 8;
     auto wptr = [&](int idx) -> const bf16x8 * {
         const int nt = idx / KS, s = idx % KS;
         return reinterpret_cast<const bf16x8 *>(wbase + ((size_t)nt * ksteps + s) * 512);
@@ -883,6 +911,20 @@ int crag_enc_v_transpose(const uint16_t *qkv, uint16_t *vt, const int32_t *tok_o
     return hip_ok("v_transpose");
 }
 
+int crag_enc_qk_rope_vt(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w, const float *cos_sin,
+                        const int32_t *positions, int64_t n_tokens, int hq, int hkv, float eps, uint16_t *vt,
+                        const int32_t *tok_of_pad, int64_t t_pad, void *stream) {
+    if (!qkv || !q_norm_w || !k_norm_w || !cos_sin || !positions || !vt || !tok_of_pad) return efail("qk_rope_vt: NULL pointer");
+    if (hq <= 0 || hkv <= 0) return efail("qk_rope_vt: bad head counts");
+    if (t_pad <= 0 || (t_pad & 31)) return efail("qk_rope_vt: t_pad must be a positive multiple of 32");
+    if (n_tokens <= 0) return 0;
+    const int rope_blocks = (int)(n_tokens < 65536 ? n_tokens : 65536);
+    const unsigned grid = (unsigned)rope_blocks + (unsigned)(t_pad / 32) * (unsigned)hkv;
+    hipLaunchKernelGGL(qk_rope_vt_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, q_norm_w, k_norm_w,
+                       cos_sin, positions, n_tokens, hq, hkv, eps, vt, tok_of_pad, t_pad, rope_blocks);
+    return hip_ok("qk_rope_vt");
+}
+
 int crag_enc_attention(const uint16_t *qkv, const uint16_t *vt, uint16_t *out, const int32_t *cu_seqlens,
                        const int32_t *cu_pad, const int32_t *blk_seq, const int32_t *blk_q0, int n_blocks,
                        int64_t t_pad, int hq, int hkv, float scale, void *stream) {
@@ -964,37 +1006,23 @@ int crag_enc_skinny_gemm(const uint16_t *x, const uint16_t *wsw, uint16_t *out, 
     hipLaunchKernelGGL((skinny_gemm_kernel<MG_, NT_, KS_, WAVES_, EPI_>), dim3((unsigned)(tiles / NT_)),      \
                        dim3(WAVES_ * 64), 0, st, p)
     const int mg = m_pad / 16;
-    // n-tiles per workgroup: every workgroup reads the activations of its K range once per NT tiles (x : W bytes =
-    // m_pad : 16 NT through the same L1 path), but tiles / NT workgroups must still cover the chip
-    int nt = epilogue ? 2 : 1;
-    if (const char *v = getenv("CRAG_SKINNY_NT")) nt = atoi(v);  // developer switch
-    if (nt < 1 || tiles % nt) return efail("skinny_gemm: %d n-tiles cannot be split %d ways", tiles, nt);
-#define CRAG_SKINNY_NT(MG_, KS_, WAVES_, EPI_)                              \
-    do {                                                                     \
-        if (nt == 1) CRAG_SKINNY(MG_, 1, KS_, WAVES_, EPI_);                 \
-        else if (nt == 2) CRAG_SKINNY(MG_, 2, KS_, WAVES_, EPI_);            \
-        else if (nt == 4) CRAG_SKINNY(MG_, 4, KS_, WAVES_, EPI_);            \
-        else return efail("skinny_gemm: n-tiles per workgroup must be 1, 2 or 4"); \
-    } while (0)
+    // n-tiles per workgroup (NT): a workgroup reads the activations of its K range once per NT tiles, but tiles / NT
+    // workgroups must still cover the chip -- measured per shape (scripts/probes/skinny_bench.py): two tiles for the
+    // wide projections (qkv 10.1 vs 10.7 us, gate|up 22.4 vs 23.1 with four), one for o and down (160 n-tiles: with
+    // two tiles per workgroup only 80 CUs work, 12.3 vs 8.4 us and 24.1 vs 16.7)
     if (k == 2560 && epilogue == 0) {
-        if (mg == 1) CRAG_SKINNY_NT(1, 10, 8, 0); else CRAG_SKINNY_NT(2, 10, 8, 0);
+        if (tiles & 1) return efail("skinny_gemm: n / 16 must be even for k = 2560");
+        if (mg == 1) CRAG_SKINNY(1, 2, 10, 8, 0); else CRAG_SKINNY(2, 2, 10, 8, 0);
     } else if (k == 2560 && epilogue == 1) {
-        if (nt == 1) nt = 2;
-        if (mg == 1) CRAG_SKINNY_NT(1, 10, 8, 1); else CRAG_SKINNY_NT(2, 10, 8, 1);
+        if (tiles & 1) return efail("skinny_gemm: the SwiGLU form needs an even number of n-tiles");
+        if (mg == 1) CRAG_SKINNY(1, 2, 10, 8, 1); else CRAG_SKINNY(2, 2, 10, 8, 1);
     } else if (k == 4096 && epilogue == 0) {
-        if (getenv("CRAG_SKINNY_W16")) {  // developer switch: 16 waves per workgroup (more loads in flight per CU)
-            if (mg == 1) CRAG_SKINNY_NT(1, 8, 16, 0); else CRAG_SKINNY_NT(2, 8, 16, 0);
-        } else {
-            if (mg == 1) CRAG_SKINNY_NT(1, 16, 8, 0); else CRAG_SKINNY_NT(2, 16, 8, 0);
-        }
+        if (mg == 1) CRAG_SKINNY(1, 1, 16, 8, 0); else CRAG_SKINNY(2, 1, 16, 8, 0);
     } else if (k == 9728 && epilogue == 0) {
-        if (mg == 1 && getenv("CRAG_SKINNY_W16")) CRAG_SKINNY_NT(1, 19, 16, 0);
-        else if (mg == 1) CRAG_SKINNY_NT(1, 38, 8, 0);
-        else CRAG_SKINNY_NT(2, 19, 16, 0);
+        if (mg == 1) CRAG_SKINNY(1, 1, 38, 8, 0); else CRAG_SKINNY(2, 1, 19, 16, 0);
     } else {
         return efail("skinny_gemm: unsupported shape k=%d epilogue=%d (built for the Qwen3-Embedding-4B widths: k = 2560 / 4096 / 9728)", k, epilogue);
     }
-#undef CRAG_SKINNY_NT
 #undef CRAG_SKINNY
     return hip_ok("skinny_gemm");
 }

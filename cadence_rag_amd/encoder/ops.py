@@ -103,3 +103,13 @@ def skinny_gemm(x: torch.Tensor, wsw: torch.Tensor, out: torch.Tensor, m_rows: i
     _native.check(_native.load().crag_enc_skinny_gemm(_p(x), _p(wsw), _p(out), int(m_rows), int(m_pad), int(n), int(k),
                                                       1 if swiglu else 0, _stream()), "crag_enc_skinny_gemm")
     return out
+
+
+def qk_rope_vt(qkv, q_w, k_w, cos_sin, positions, hq: int, hkv: int, eps: float, vt, tok_of_pad):
+    """qk_norm_rope (in place on q|k) and v_transpose (v -> vt) in one launch."""
+    _req(qkv, torch.bfloat16, "qkv"); _req(cos_sin, torch.float32, "cos_sin"); _req(positions, torch.int32, "positions")
+    _req(vt, torch.bfloat16, "vt"); _req(tok_of_pad, torch.int32, "tok_of_pad")
+    _native.check(_native.load().crag_enc_qk_rope_vt(_p(qkv), _p(q_w), _p(k_w), _p(cos_sin), _p(positions),
+                                                     positions.numel(), hq, hkv, float(eps), _p(vt), _p(tok_of_pad),
+                                                     tok_of_pad.numel(), _stream()), "crag_enc_qk_rope_vt")
+    return qkv

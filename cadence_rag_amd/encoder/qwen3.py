@@ -273,9 +273,8 @@ class Qwen3Encoder:
             for lo in range(0, t if skinny is None else 0, QKV_ROW_CHUNK):
                 hi = min(t, lo + QKV_ROW_CHUNK)
                 torch.matmul(normed[lo:hi], L["qkv"].t(), out=qkv[lo:hi])
-            ops.qk_norm_rope(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
-                             c.num_heads, c.num_kv_heads, c.rms_norm_eps)
-            ops.v_transpose(qkv_buf, vt, batch.tok_of_pad, c.num_heads, c.num_kv_heads)
+            ops.qk_rope_vt(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
+                           c.num_heads, c.num_kv_heads, c.rms_norm_eps, vt, batch.tok_of_pad)
             ops.attention(qkv_buf, vt, attn, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0,
                           c.num_heads, c.num_kv_heads, scale)
             if last_only and i == len(self.layers) - 1:

@@ -88,6 +88,11 @@ int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *d
 int crag_enc_skinny_gemm(const uint16_t *x, const uint16_t *wsw, uint16_t *out, int m_rows, int m_pad, int n, int k,
                          int epilogue, void *stream);
 
+/* crag_enc_qk_norm_rope and crag_enc_v_transpose in ONE launch (disjoint columns of the fused qkv rows). */
+int crag_enc_qk_rope_vt(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w, const float *cos_sin,
+                        const int32_t *positions, int64_t n_tokens, int hq, int hkv, float eps, uint16_t *vt,
+                        const int32_t *tok_of_pad, int64_t t_pad, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,6 +311,27 @@ def test_skinny_gemm_streams_the_weights_for_one_short_query(gpu, k, n, swiglu, 
         assert torch.allclose(got, want, atol=3e-3, rtol=3e-2), (got - want).abs().max()
 
 
+def test_rope_and_v_transpose_in_one_launch_equal_the_two_kernels(gpu):
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch, Qwen3Config, Qwen3Encoder
+    g = torch.Generator().manual_seed(99)
+    hq, hkv = 8, 2
+    lens = [5, 40, 1, 33]
+    batch = PackedBatch.build(lens, DEV)
+    t = batch.n_tokens
+    qkv = torch.randn(t + 32, (hq + 2 * hkv) * 128, generator=g).to(BF).to(DEV)
+    qw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF).to(DEV)
+    kw = (1 + 0.1 * torch.randn(128, generator=g)).to(BF).to(DEV)
+    cos_sin = Qwen3Encoder._rope_table(Qwen3Config(max_length=64)).to(DEV)
+    a, b = qkv.clone(), qkv.clone()
+    vt_a = torch.zeros(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+    vt_b = torch.zeros_like(vt_a)
+    ops.qk_norm_rope(a, qw, kw, cos_sin, batch.positions, hq, hkv, 1e-6)
+    ops.v_transpose(a, vt_a, batch.tok_of_pad, hq, hkv)
+    ops.qk_rope_vt(b, qw, kw, cos_sin, batch.positions, hq, hkv, 1e-6, vt_b, batch.tok_of_pad)
+    assert torch.equal(a, b) and torch.equal(vt_a, vt_b)
+
+
 def test_small_batches_replay_one_graph_per_shape_and_match_the_eager_forward(gpu, monkeypatch):
     """A /retrieve request embeds one short query: embed_token_lists pads every sequence behind its last real token
     to a bucket length and replays a captured graph per (sequences, bucket).  Same embeddings as the eager packed
