@@ -599,6 +599,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
+    ap.add_argument("--no-overlap-leg", action="store_true",
+                    help="skip the 2- and 3-stream repeats of the headline leg (profiling runs: overlapped launches of "
+                         "the same kernel would be averaged into its rocprofv3 duration)")
     ap.add_argument("--no-hybrid", action="store_true", help="skip the configs[4] hybrid leg (N = 1, with target_1m)")
     ap.add_argument("--no-query-path", action="store_true",
                     help="skip the reference-operating-point leg (encode 1/8/64 queries -> top-50 + top-10 searches)")
@@ -719,7 +722,8 @@ def main() -> None:
 
     overlap = fp32_leg = None
     if world == 1:
-        overlap = {str(n): overlap_leg(index, queries, k, n, args.steps) for n in (2, 3)}
+        if not args.no_overlap_leg:
+            overlap = {str(n): overlap_leg(index, queries, k, n, args.steps) for n in (2, 3)}
         if index.prefilter_row_bytes() == DIM * 2 and not args.no_fp32_rows_leg:
             fp32_leg = fp32_rows_leg(corpus, ids, queries, k, dev_index, max(200, args.steps // 4), leg["out"], traffic_doc)
     target = hybrid = query_path = shared_enc = None

@@ -20,8 +20,8 @@ CRAG_BENCH_BACKEND=gloo timeout -k 10 240 python -m torch.distributed.run --nnod
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
 # the headline leg alone (in the full command above the 1M legs launch the same kernel template)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -- python3 $R/bench.py --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg > /dev/null 2> $O/stats_headline.err
-B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -- python3 $R/bench.py --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg --no-overlap-leg > /dev/null 2> $O/stats_headline.err
+B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg --no-overlap-leg"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64 -- python3 $R/bench.py $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
