@@ -80,7 +80,8 @@ struct PfParams {
     uint32_t seq;             // this search's sequence number on its workspace (never 0)
     int64_t n_rows;
     int nq, k, G, reverse;
-    int sets;                 // 1, 2 or 4 class sets (<= k)
+    int sets;                 // 1, 2 or 4 class sets (32 * sets >= k)
+    int pub0;                 // rows of a workgroup's FIRST tile that publish their score per query (sets > 1): sets, or 8
     int nt;                   // corpus loads with the streaming cache policy (corpus larger than the Infinity Cache)
     int cap;
 };

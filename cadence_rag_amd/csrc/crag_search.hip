@@ -2029,7 +2029,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                             lift = lift && (v == half_max_u32(v));
                         } else {  // the tile's SETS best rows: a workgroup's first tile feeds one of the SETS sets
                             const uint32_t sorted = sort32_desc_u32(v, lane);
-                            lift = lift && (v >= (uint32_t)__shfl((int)sorted, (lane & 32) | (SETS - 1)));
+                            // (pub0 = SETS, or 8 when k_s nears 32: the bound then needs nearly EVERY class of the
+                            // set to be populated after this first exchange -- with SETS rows per workgroup 4 % of the
+                            // queries of a k = 128 search found a class still empty, passed every row of the next
+                            // three tiles and pushed the whole search into the fallback)
+                            lift = lift && (v >= (uint32_t)__shfl((int)sorted, (lane & 32) | (p.pub0 - 1)));
                         }
                     }
                     if (lift)
