@@ -2159,7 +2159,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         if (__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq) return;
         const int b = (int)blockIdx.x - p.nq * R;
         scan_body<S>(p.scan, b % p.scan.G, b / p.scan.G, U.slab);
-        // every wave's list stores are drained at the barrier; one lane releases them and draws a ticket
+        // every wave drains its own list stores, then the barrier; one lane releases them and draws a ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -2435,7 +2436,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             }
         }
         if (tid == 0) p.xcount[(size_t)q * R + rpart] = make_uint2((uint32_t)(B < k ? B : k), (uint32_t)s_rescored);
-        __syncthreads();  // (drains every wave's stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own stores, then the barrier
+        __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

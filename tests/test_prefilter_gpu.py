@@ -308,3 +308,42 @@ def test_selection_shared_by_several_blocks_per_query_equals_one_block(gpu, monk
     want = oracle.exact_topk(q[:s], corpus, k, mode=oracle.F64, fast=True)
     got = out[True][0][0]
     assert_topk_matches(got[0][:s], got[1][:s], got[2][:s], *want, tol=TOL)
+
+
+def test_hand_offs_under_load_four_streams_overflow_and_shared_selection(gpu, monkeypatch):
+    """The two in-launch hand-offs of the selection kernel -- the fallback's "last block merges" and the R blocks per
+    query of a large-k selection -- with the device busy: four streams launch overflowing searches, top-100 / top-50
+    searches and plain ones back to back without synchronising.  Every answer equals the single-stream answer."""
+    import torch
+    rng = np.random.default_rng(31337)
+    n = 60_000
+    corpus = unit_rows(rng, n)
+    corpus[8_000:30_000] = corpus[11]                    # 22 000 duplicates
+    base = rng.standard_normal((64, 1024)).astype(np.float32)
+    base -= np.outer(base @ corpus[11], corpus[11])
+    jobs = [(np.concatenate([corpus[11][None] * 3.0, base[:9]]), 10),      # overflows -> fallback blocks
+            (base, 10), (base[:7], 100), (base[:20], 50), (base[:33], 10), (base[:1], 64)]
+    dev = torch.device("cuda", 0)
+    ix = _index(corpus, monkeypatch)
+    try:
+        want = [ix.search(q, k) for q, k in jobs]
+        assert want[0][0][0].tolist() == [11] + list(range(8_000, 8_009))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        dq = [torch.from_numpy(q).to(dev) for q, _ in jobs]
+        torch.cuda.synchronize()
+        outs = []
+        for rep in range(6):
+            for si, st in enumerate(streams):
+                i = (si * 2 + rep) % len(jobs)
+                nq, k = len(jobs[i][0]), jobs[i][1]
+                o = (torch.empty(nq, k, dtype=torch.int64, device=dev), torch.empty(nq, k, dtype=torch.float32, device=dev),
+                     torch.empty(nq, dtype=torch.int32, device=dev))
+                ix.search_async(dq[i], k, *o, stream=st.cuda_stream)
+                outs.append((i, o))
+        torch.cuda.synchronize()
+        for i, o in outs:
+            assert np.array_equal(o[0].cpu().numpy(), want[i][0]), i
+            assert np.array_equal(o[1].cpu().numpy(), want[i][1], equal_nan=True), i
+            assert np.array_equal(o[2].cpu().numpy(), want[i][2]), i
+    finally:
+        ix.close()
