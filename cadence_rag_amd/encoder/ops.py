@@ -113,3 +113,41 @@ def qk_rope_vt(qkv, q_w, k_w, cos_sin, positions, hq: int, hkv: int, eps: float,
                                                      positions.numel(), hq, hkv, float(eps), _p(vt), _p(tok_of_pad),
                                                      tok_of_pad.numel(), _stream()), "crag_enc_qk_rope_vt")
     return qkv
+
+
+# -- the layer at 16 / 32 token rows as five launches (csrc/crag_encoder_small.hip) -------------------------------
+def small_weight(weight: torch.Tensor, rows: int) -> torch.Tensor:
+    """[n, k] bf16 (torch Linear layout) -> the tile order crag_enc_small_gemm streams:
+    [n / rows][k / 32][4][rows][8]; n % rows == 0, k % 32 == 0.  rows = 16 is skinny_weight's order."""
+    n, k = weight.shape
+    if n % rows or k % 32:
+        raise ValueError(f"weight [{n}, {k}] does not split into {rows}-row tiles of 32-element k-steps")
+    return weight.view(n // rows, rows, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def small_gemm(x: torch.Tensor, wsw: torch.Tensor, out: torch.Tensor, m_rows: int, n: int, rows: int, *,
+               swiglu: bool = False, delta=None, norm_w=None, res_out=None, eps: float = 1e-6):
+    """out[m_rows, n (or n/2)] = X @ W^T for 16 or 32 rows; with norm_w: X = RMSNorm(x + delta) * norm_w computed in
+    the kernel's prologue, res_out <- x + delta (crag_enc_small_gemm)."""
+    _req(x, torch.bfloat16, "x"); _req(wsw, torch.bfloat16, "wsw"); _req(out, torch.bfloat16, "out")
+    for name, t in (("delta", delta), ("norm_w", norm_w), ("res_out", res_out)):
+        if t is not None:
+            _req(t, torch.bfloat16, name)
+    m_pad, k = x.shape
+    _native.check(_native.load().crag_enc_small_gemm(_p(x), _p(delta), _p(norm_w), _p(res_out), _p(wsw), _p(out),
+                                                     int(m_rows), int(m_pad), int(n), int(k), int(rows),
+                                                     1 if swiglu else 0, float(eps), _stream()), "crag_enc_small_gemm")
+    return out
+
+
+def small_attention(qkv, q_w, k_w, cos_sin, positions, out, hq: int, hkv: int, eps: float, scale: float,
+                    by_token: bool = False):
+    """q/k-norm + RoPE + causal attention of <= 32 packed token rows (crag_enc_small_attention); qkv is not modified.
+    by_token: cos_sin holds the table rows of the tokens' positions, [T, 64, 2]."""
+    _req(qkv, torch.bfloat16, "qkv"); _req(cos_sin, torch.float32, "cos_sin"); _req(positions, torch.int32, "positions")
+    _req(out, torch.bfloat16, "out"); _req(q_w, torch.bfloat16, "q_w"); _req(k_w, torch.bfloat16, "k_w")
+    _native.check(_native.load().crag_enc_small_attention(_p(qkv), _p(q_w), _p(k_w), _p(cos_sin), 1 if by_token else 0,
+                                                          _p(positions), _p(out),
+                                                          positions.numel(), hq, hkv, float(eps), float(scale),
+                                                          _stream()), "crag_enc_small_attention")
+    return out

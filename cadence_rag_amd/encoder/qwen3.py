@@ -223,18 +223,68 @@ class Qwen3Encoder:
 
     # -- 16 / 32 tokens: the linear layers as weight streams ------------------------------------------------
     def _skinny_weights(self) -> Optional[List[Dict[str, torch.Tensor]]]:
-        """The four projections of every layer a second time, in the fragment order crag_enc_skinny_gemm streams
+        """The four projections of every layer a second time, in the tile order the weight-streaming kernels read
         (+ 100 % of the layer weights in HBM: 8 GB for the 4B model), built on first use.  None when the model's
-        widths are not the ones the kernel is built for or CRAG_ENC_NO_SKINNY is set."""
+        widths are not the ones the kernels are built for or CRAG_ENC_NO_SKINNY is set.  Default: the five-launch
+        layer of csrc/crag_encoder_small.hip (tile heights 12 / 10 / 16 / 10 rows for qkv / o / gate|up / down, so
+        that the tiles of a projection cover the 256 CUs evenly); CRAG_ENC_SMALL_V1=1 keeps round 3's first version
+        (crag_enc_skinny_gemm, 16-row tiles, eight launches per layer) for A/B measurements."""
         c = self.cfg
         if (os.environ.get("CRAG_ENC_NO_SKINNY") is not None or c.hidden_size != 2560 or c.q_size != 4096
-                or c.intermediate_size != 9728 or (c.q_size + 2 * c.kv_size) % 16):
+                or c.intermediate_size != 9728 or (c.q_size + 2 * c.kv_size) != 6144 or c.head_dim != 128):
             return None
-        if self.__dict__.get("_skinny") is None:
-            self._skinny = [{"qkv": ops.skinny_weight(L["qkv"]), "o": ops.skinny_weight(L["o"]),
-                             "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.skinny_weight(L["down"])}
-                            for L in self.layers]
+        v1 = os.environ.get("CRAG_ENC_SMALL_V1") is not None
+        if self.__dict__.get("_skinny") is None or self.__dict__.get("_skinny_v1") != v1:
+            self._skinny = None
+            self.__dict__.pop("_graphs", None)   # graphs captured over the other kernels
+            if v1:
+                self._skinny = [{"qkv": ops.skinny_weight(L["qkv"]), "o": ops.skinny_weight(L["o"]),
+                                 "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.skinny_weight(L["down"])}
+                                for L in self.layers]
+            else:
+                self._skinny = [{"qkv": ops.small_weight(L["qkv"], 12), "o": ops.small_weight(L["o"], 10),
+                                 "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.small_weight(L["down"], 10)}
+                                for L in self.layers]
+            self._skinny_v1 = v1
         return self._skinny
+
+    @torch.no_grad()
+    def _forward_small_rows(self, x: torch.Tensor, batch: PackedBatch, skinny) -> torch.Tensor:
+        """The 36 layers at 16 or 32 token rows, five launches each (csrc/crag_encoder_small.hip): the residual add and
+        the RMSNorm run in the prologue of the projection that consumes them, q/k-norm + RoPE inside the attention
+        kernel.  x: [T, hidden] embedding rows (consumed as the first residual stream)."""
+        c, dev, bf = self.cfg, self.device, torch.bfloat16
+        t = batch.n_tokens
+        width = c.q_size + 2 * c.kv_size
+        res_a, res_b = x, torch.empty_like(x)
+        delta = torch.zeros(t, c.hidden_size, dtype=bf, device=dev)      # "no delta yet" in front of layer 0
+        delta_o = torch.empty_like(delta)
+        delta_d = torch.empty_like(delta)
+        qkv = torch.empty(t, width, dtype=bf, device=dev)
+        attn = torch.empty(t, c.q_size, dtype=bf, device=dev)
+        act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
+        scale = 1.0 / math.sqrt(c.head_dim)
+        cs_tok = self._cos_sin.index_select(0, batch.positions.long())   # once per forward, not once per layer
+        for i, L in enumerate(self.layers):
+            W = skinny[i]
+            ops.small_gemm(res_a, W["qkv"], qkv, t, width, 12, delta=delta if i == 0 else delta_d, norm_w=L["ln1"],
+                           res_out=res_b, eps=c.rms_norm_eps)
+            ops.small_attention(qkv, L["q_norm"], L["k_norm"], cs_tok, batch.positions, attn, c.num_heads,
+                                c.num_kv_heads, c.rms_norm_eps, scale, by_token=True)
+            ops.small_gemm(attn, W["o"], delta_o, t, c.hidden_size, 10)
+            ops.small_gemm(res_b, W["gate_up"], act, t, 2 * c.intermediate_size, 16, swiglu=True, delta=delta_o,
+                           norm_w=L["ln2"], res_out=res_a, eps=c.rms_norm_eps)
+            ops.small_gemm(act, W["down"], delta_d, t, c.hidden_size, 10)
+        out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
+        if c.pooling == "last":
+            # the pooled rows are DATA (batch.last_tok: in a graph replay the real last token of every padded sequence)
+            ops.pool_normalize(res_a.index_select(0, batch.last_tok), self.final_norm, batch.cu_one, out, c.out_dim, 0,
+                               c.rms_norm_eps, delta=delta_d.index_select(0, batch.last_tok))
+        else:
+            normed = torch.empty_like(x)
+            ops.rmsnorm(delta_d, self.final_norm, normed, c.rms_norm_eps, residual_in=res_a, residual_out=None)
+            ops.pool_normalize(normed, None, batch.cu, out, c.out_dim, 1, c.rms_norm_eps)
+        return out
 
     # -- forward --------------------------------------------------------------------------------
     @torch.no_grad()
@@ -247,6 +297,10 @@ class Qwen3Encoder:
         bf = torch.bfloat16
         x = torch.empty(t, c.hidden_size, dtype=bf, device=dev)
         ops.embed_gather(ids, self.embed, x)
+        # 16 or 32 tokens (one short query): the projections stream their weights (crag_encoder_small.hip)
+        skinny = self._skinny_weights() if t in (16, 32) else None
+        if skinny is not None and not self._skinny_v1:
+            return self._forward_small_rows(x, batch, skinny)
         resid = torch.empty_like(x)
         normed = torch.empty_like(x)
         width = c.q_size + 2 * c.kv_size
@@ -257,8 +311,6 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
-        # 16 or 32 tokens (one short query): the projections stream their weights through crag_enc_skinny_gemm
-        skinny = self._skinny_weights() if t in (16, 32) else None
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         for i, L in enumerate(self.layers):
             if i == 0:

@@ -93,6 +93,34 @@ int crag_enc_qk_rope_vt(uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t 
                         const int32_t *positions, int64_t n_tokens, int hq, int hkv, float eps, uint16_t *vt,
                         const int32_t *tok_of_pad, int64_t t_pad, void *stream);
 
+/* ---- the decoder layer at 16 / 32 token rows (one short query per /retrieve request, retrieve.py:427) as five
+ * launches: csrc/crag_encoder_small.hip ----
+ *
+ * crag_enc_small_gemm: out[m_rows, n (or n/2)] = X[m_pad, k] @ W[n, k]^T with the weights streamed once from HBM.
+ *   wsw: W in tile order [n / rows_per_tile][k / 32][4][rows_per_tile][8] (a tile's k-step is one contiguous block
+ *        whose 16-byte pieces are the MFMA A-operand registers of a lane);  rows_per_tile in {10, 12, 16}.
+ *   norm_w != NULL (RMSNorm prologue, k = 2560): X = weight * bf16((x + delta) * rsqrt(mean((x + delta)^2) + eps)),
+ *        the sum x + delta rounded to bf16 first (the residual stream); delta is required (zeros for none);
+ *        res_out (nullable, must not alias x or delta) receives x + delta.
+ *   norm_w == NULL: X = x; delta and res_out must be NULL.
+ *   epilogue 1 (rows_per_tile 16): a tile is 8 gate rows then the 8 up rows of the same features; out [m_rows, n/2]
+ *        = silu(gate) * up with crag_enc_swiglu's roundings.
+ * Built for the Qwen3-Embedding-4B widths: (k 2560, prologue, 12-row tiles), (k 2560, prologue, SwiGLU, 16-row
+ * tiles), (k 4096, 10-row tiles), (k 9728, 10-row tiles).  m_pad = 16 or 32 rows are read, m_rows written. */
+int crag_enc_small_gemm(const uint16_t *x, const uint16_t *delta, const uint16_t *norm_w, uint16_t *res_out,
+                        const uint16_t *wsw, uint16_t *out, int m_rows, int m_pad, int n, int k, int rows_per_tile,
+                        int epilogue, float eps, void *stream);
+
+/* Per-head q/k RMSNorm + RoPE (crag_enc_qk_norm_rope's arithmetic) + causal attention for n_tokens <= 32 packed
+ * token rows in one launch, one workgroup per q head.  qkv[T, (hq + 2 hkv) * 128] holds the raw projections and is
+ * not modified; positions[T] (position inside its sequence) also tells the sequences apart: tokens t and u belong
+ * to the same sequence iff t - positions[t] == u - positions[u].  cos_sin: the [max_pos, 64, 2] table of
+ * crag_enc_qk_norm_rope, or with cos_sin_by_token != 0 its rows gathered per token, [T, 64, 2] (done once per forward
+ * it takes a dependent load out of every layer).  out[T, hq * 128]. */
+int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w,
+                             const float *cos_sin, int cos_sin_by_token, const int32_t *positions, uint16_t *out,
+                             int n_tokens, int hq, int hkv, float eps, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -507,6 +507,124 @@ def test_full_depth_36_layers_match_transformers_qwen3(gpu):
     del model
 
 
+# ------------------------------------------------------------------------------------------------------
+# the layer at 16 / 32 token rows as five launches (csrc/crag_encoder_small.hip)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,n,rows,swiglu,pro", [(2560, 6144, 12, False, True), (2560, 19456, 16, True, True),
+                                                  (4096, 2560, 10, False, False), (9728, 2560, 10, False, False)])
+@pytest.mark.parametrize("m_rows,m_pad", [(1, 16), (16, 16), (17, 32), (32, 32)])
+def test_small_gemm_with_fused_residual_rmsnorm_and_swiglu(gpu, k, n, rows, swiglu, pro, m_rows, m_pad):
+    """crag_enc_small_gemm, the four forms the 4B layer uses: tiles of 12 / 16 / 10 / 10 weight rows, the residual
+    add + RMSNorm prologue (against crag_enc_rmsnorm: the residual sum bit for bit, the projection against torch on
+    the unfused kernel's normalised rows) and the SwiGLU epilogue (against crag_enc_swiglu's arithmetic).  Padding
+    rows may hold anything and never reach an output."""
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(k + n + 7 * m_rows)
+    x = torch.randn(m_pad, k, generator=g) * 2
+    d = torch.randn(m_pad, k, generator=g) * 0.5
+    x[m_rows:] = float("nan")
+    w = (torch.randn(n, k, generator=g) * 0.02).to(BF)
+    nw = _bf(1 + 0.1 * torch.randn(k, generator=g))
+    xd, dd, wd = _bf(x), _bf(d), w.to(DEV)
+    wsw = ops.skinny_gate_up_weight(wd) if swiglu else ops.small_weight(wd, rows)
+    n_out = n // 2 if swiglu else n
+    out = torch.full((m_rows + 1, n_out), 7.0, dtype=BF, device=DEV)
+    if pro:
+        res = torch.full((m_pad + 1, k), 5.0, dtype=BF, device=DEV)
+        ops.small_gemm(xd, wsw, out[:m_rows], m_rows, n, rows, swiglu=swiglu, delta=dd, norm_w=nw, res_out=res[:m_pad],
+                       eps=1e-6)
+        normed = torch.empty(m_rows, k, dtype=BF, device=DEV)
+        want_res = torch.empty(m_rows, k, dtype=BF, device=DEV)
+        ops.rmsnorm(dd[:m_rows].contiguous(), nw, normed, 1e-6, residual_in=xd[:m_rows].contiguous(), residual_out=want_res)
+        assert torch.equal(res[:m_rows], want_res)                  # the residual stream: bit for bit
+        assert torch.all(res[m_pad] == 5.0) and torch.all(res[m_rows:m_pad] == 5.0)
+        # the fused norm sums the squares in another order: a normalised element may land on the neighbouring bf16
+        a = normed.float().cpu()
+    else:
+        ops.small_gemm(xd, wsw, out[:m_rows], m_rows, n, rows)
+        a = xd[:m_rows].float().cpu()
+    assert torch.all(out[m_rows] == 7.0)                            # nothing written behind the real rows
+    ref = a @ w.float().t()
+    if not swiglu:
+        got = out[:m_rows].float().cpu()
+        scale = ref.abs().max()
+        assert torch.allclose(got, ref, atol=float(scale) * 2 ** -6, rtol=1.2e-2), (got - ref).abs().max()
+    else:
+        want = torch.empty(m_rows, n_out, dtype=BF, device=DEV)
+        ops.swiglu(ref.to(BF).to(DEV).contiguous(), want)
+        got, want = out[:m_rows].float().cpu(), want.float().cpu()
+        assert torch.allclose(got, want, atol=float(want.abs().max()) * 2 ** -5, rtol=4e-2), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("lens", [[16], [1], [5], [32], [17], [16, 16], [7, 9], [3, 20, 9], [1, 1, 1, 1]])
+def test_small_attention_fuses_qk_norm_rope_and_causal_attention(gpu, lens):
+    """crag_enc_small_attention (<= 32 packed token rows, one workgroup per q head) against the fp32 reference of
+    per-head RMSNorm -> RoPE -> causal softmax attention per sequence, and against the two unfused kernels
+    (crag_enc_qk_norm_rope + crag_enc_attention) it replaces on that path."""
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch, Qwen3Config, Qwen3Encoder
+    hq, hkv = 32, 8
+    g = torch.Generator().manual_seed(sum(lens) * 13 + len(lens))
+    t = sum(lens)
+    qkv = _bf(torch.randn(t + 32, (hq + 2 * hkv) * 128, generator=g))
+    qw, kw = _bf(1 + 0.1 * torch.randn(128, generator=g)), _bf(1 + 0.1 * torch.randn(128, generator=g))
+    cfg = Qwen3Config(max_length=64)
+    table = Qwen3Encoder._rope_table(cfg).to(DEV)
+    batch = PackedBatch.build(lens, DEV)
+    before = qkv.clone()
+    out = torch.full((t + 1, hq * 128), 9.0, dtype=BF, device=DEV)
+    ops.small_attention(qkv[:t], qw, kw, table, batch.positions, out[:t], hq, hkv, 1e-6, 1 / math.sqrt(128))
+    assert torch.equal(qkv, before) and torch.all(out[t] == 9.0)
+    by_tok = torch.empty_like(out)                                # the table's rows gathered per token: same bits
+    ops.small_attention(qkv[:t], qw, kw, table.index_select(0, batch.positions.long()), batch.positions, by_tok[:t], hq,
+                        hkv, 1e-6, 1 / math.sqrt(128), by_token=True)
+    assert torch.equal(by_tok[:t], out[:t])
+    got = out[:t].float().cpu().view(t, hq, 128)
+    assert torch.isfinite(got).all()
+    pos = batch.positions.cpu()
+
+    def normed(block, w, heads):
+        v = block.float().cpu().view(t, heads, 128)
+        return _rope_ref(v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float().cpu(), pos, cfg.rope_theta)
+
+    ref = _attn_ref(normed(before[:t, : hq * 128], qw, hq), normed(before[:t, hq * 128: (hq + hkv) * 128], kw, hkv),
+                    before[:t, (hq + hkv) * 128:].float().cpu().view(t, hkv, 128), lens, hq, hkv)
+    assert torch.allclose(got, ref, atol=3e-2, rtol=3e-2), (lens, (got - ref).abs().max())
+    # the kernels it replaces
+    vt = torch.empty(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+    ops.qk_rope_vt(qkv, qw, kw, table, batch.positions, hq, hkv, 1e-6, vt, batch.tok_of_pad)
+    old = torch.empty(t, hq * 128, dtype=BF, device=DEV)
+    ops.attention(qkv, vt, old, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
+    assert torch.allclose(got, old.float().cpu().view(t, hq, 128), atol=2e-2, rtol=2e-2)
+
+
+def test_one_short_query_takes_the_five_launch_layer_and_matches_transformers(gpu, monkeypatch):
+    """Real 4B widths, two layers, the shapes of the reference's operating point (one query of <= 16 tokens; also one
+    of <= 32 and two of <= 16): embed_token_lists replays the graph of the five-launch layer
+    (crag_encoder_small.hip).  Against transformers' Qwen3Model in fp32 (the bars of the real-width test above) and
+    against the eager packed forward through the library GEMMs and the unfused kernels."""
+    model, enc, cfg = _real_width_hf_and_mine()
+    rng = np.random.default_rng(5)
+    for lens in ([9], [16], [1], [20], [32], [5, 16], [12, 3]):
+        token_lists = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
+        monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
+        monkeypatch.delenv("CRAG_ENC_NO_SKINNY", raising=False)
+        fast = enc.embed_token_lists(token_lists)
+        assert torch.equal(fast, enc.embed_token_lists(token_lists))
+        assert enc._skinny is not None and not enc._skinny_v1
+        monkeypatch.setenv("CRAG_ENC_NO_GRAPH", "1")
+        monkeypatch.setenv("CRAG_ENC_NO_SKINNY", "1")
+        eager = enc.embed_token_lists(token_lists)
+        want = _hf_embed(model, cfg, token_lists, "last")
+        diff = (fast.cpu() - want).abs()
+        print(f"\nfive-launch layer {lens}: vs transformers max |d| = {diff.max():.2e}, rms = "
+              f"{diff.pow(2).mean().sqrt():.2e}; vs eager max |d| = {(fast - eager).abs().max():.2e}")
+        assert torch.allclose(fast.norm(dim=1).cpu(), torch.ones(len(lens)), atol=1e-5)
+        assert diff.pow(2).mean().sqrt() <= 6.5e-4 and diff.max() <= 3e-3, lens
+        assert ((fast.cpu() * want).sum(-1)).min() >= 0.9998, lens
+        assert (fast - eager).abs().max() <= 3e-3, lens
+
+
 def test_backfill_through_native_encoder_into_hbm_index(gpu, monkeypatch):
     """BASELINE configs[3] shape on one GPU: run_embedding_backfill (embedding_pipeline.py:241) at batch 256 over
     chunks of ~256 tokens, through embed_texts -> the native encoder at the 4B widths (4 layers: the per-layer
