@@ -118,20 +118,14 @@ __global__ __launch_bounds__(WAVES * 64) void small_gemm_kernel(SmallGemmParams 
         }
     };
     // weights: a (tile, k-step) block is 4 k-groups x R rows x 8 elements; lanes of the rows a short tile lacks
-    // re-read its last row.  Without a prologue the first D weight loads leave BEFORE the activation loads: they
-    // have the HBM latency in front of them, the activations come from L2 meanwhile (loads return in issue order, and
-    // the weights are needed no earlier than the activations).  With the RMSNorm prologue the activations go first:
-    // the norm is computed while the weights are on their way.
+    // re-read its last row.  The activation loads go first (L2; with the prologue the norm is computed while the
+    // weights are on their way from HBM).  [Measured: the first D weight loads in front of the activation loads,
+    // 7.5 -> 8.4 us for the o projection, no change for down.]
     const int crow = c < R ? c : R - 1;
     const u16 *wlane = p.wsw + (size_t)kw0 * (32 * R) + (size_t)(g * R + crow) * 8;
     auto wptr = [&](int t, int s) -> const bf16x8 * {
         return reinterpret_cast<const bf16x8 *>(wlane + ((size_t)t * KSTEPS + s) * (32 * R));
     };
-    bf16x8 wr[D];
-    if constexpr (!PRO) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(tile, i));
-    }
     load_x(0);
     bf16x8 dl[PRO ? MG : 1][PRO ? KS : 1];
     if constexpr (PRO) {
@@ -143,9 +137,10 @@ __global__ __launch_bounds__(WAVES * 64) void small_gemm_kernel(SmallGemmParams 
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) nw[s] = *reinterpret_cast<const bf16x8 *>(p.norm_w + (size_t)(kw0 + s) * 32 + 8 * g);
-#pragma unroll
-        for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(tile, i));
     }
+    bf16x8 wr[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(tile, i));
 
     if constexpr (PRO) {
 #pragma unroll
