@@ -135,12 +135,16 @@ __global__ __launch_bounds__(WAVES * 64) void small_gemm_kernel(SmallGemmParams 
 #pragma unroll
             for (int s = 0; s < KS; ++s) dl[mg][s] = *reinterpret_cast<const bf16x8 *>(dr + 32 * s);
         }
+        if constexpr (MG == 1) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) nw[s] = *reinterpret_cast<const bf16x8 *>(p.norm_w + (size_t)(kw0 + s) * 32 + 8 * g);
+            for (int s = 0; s < KS; ++s) nw[s] = *reinterpret_cast<const bf16x8 *>(p.norm_w + (size_t)(kw0 + s) * 32 + 8 * g);
+        }
     }
     bf16x8 wr[D];
+    if constexpr (!(PRO && MG > 1)) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(tile, i));
+        for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(tile, i));
+    }
 
     if constexpr (PRO) {
 #pragma unroll
@@ -166,7 +170,15 @@ __global__ __launch_bounds__(WAVES * 64) void small_gemm_kernel(SmallGemmParams 
             ss += __shfl_xor(ss, 32);
             if (lane < 16) nrm[w][mg][c] = ss;
         }
+        if constexpr (MG > 1) {  // 32 rows: x and delta fill the register file; the ring starts when delta is dead
+#pragma unroll
+            for (int i = 0; i < D; ++i) wr[i] = __builtin_nontemporal_load(wptr(tile, i));
+        }
         __syncthreads();
+        if constexpr (MG > 1) {  // ... and the norm weights come last
+#pragma unroll
+            for (int s = 0; s < KS; ++s) nw[s] = *reinterpret_cast<const bf16x8 *>(p.norm_w + (size_t)(kw0 + s) * 32 + 8 * g);
+        }
 #pragma unroll
         for (int mg = 0; mg < MG; ++mg) {
             float tot = 0.f;

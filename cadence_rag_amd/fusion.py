@@ -204,13 +204,20 @@ class HybridSearcher:
     lane order bm25 -> tech_tokens -> dense."""
 
     def __init__(self, index, tech_index: "TechTokenIndex | None" = None, *, dense_k: int = 50, tech_k: int = 50,
-                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False) -> None:
+                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False, overlap_lanes: bool = True) -> None:
         """verify_tokens: run the exact-token lane's host-side string check (a blocking D2H copy per step); off by
-        default so that a step only enqueues work on the caller's stream."""
+        default so that a step only enqueues work on the caller's stream.
+        overlap_lanes: the exact-token lane runs on a side stream BESIDE the dense scan (the two lanes are
+        independent until the fusion: retrieve.py:455-487 issues them one after the other only because SQL does);
+        its 28 bytes per row ride along with the scan's 2 KiB per row.  The side stream forks from the caller's
+        stream at the start of a call and joins it again in front of the fusion kernel, so to the caller a step is
+        still work enqueued on ITS stream."""
         self.index, self.tech = index, tech_index
         self.verify_tokens = bool(verify_tokens)
+        self.overlap_lanes = bool(overlap_lanes)
         self.dense_k, self.tech_k, self.rrf_k = int(dense_k), int(tech_k), int(rrf_k)
         self._dense_out: dict = {}  # per (stream, batch size): results of calls on different streams stay apart
+        self._side: dict = {}       # per caller stream: (side stream, fork event, join event)
 
     def search(self, query_vectors: torch.Tensor, query_token_lists=None, bm25=None, *, out_k: int = 0,
                row_mask=None, mask_stride: int = 0, stream: int = 0) -> Dict[str, torch.Tensor]:
@@ -229,12 +236,30 @@ class HybridSearcher:
                                                  torch.empty(nq, self.dense_k, dtype=torch.float32, device=dev),
                                                  torch.empty(nq, dtype=torch.int32, device=dev))
         d_ids, d_sc, d_ct = self._dense_out[(stream, nq)]
+        use_tech = self.tech is not None and query_token_lists is not None
+        tech_lane = None
+        if use_tech and self.overlap_lanes and not self.verify_tokens:
+            # fork: everything the caller enqueued so far (queries, masks, the previous step's fusion, which may
+            # still read the side stream's recycled buffers) is ordered before the side stream's work
+            if stream not in self._side:
+                self._side[stream] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+            side, fork, join = self._side[stream]
+            with _on_stream(stream, dev):
+                fork.record()
+            side.wait_event(fork)
+            tech_lane = self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
+                                         stream=side.cuda_stream, verify=False)
+            join.record(side)
         self.index.search_async(query_vectors, self.dense_k, d_ids, d_sc, d_ct, d_row_mask=row_mask,
                                 mask_stride=mask_stride, stream=stream)
         lanes = []
         if bm25 is not None:
             lanes.append(bm25)
-        if self.tech is not None and query_token_lists is not None:
+        if tech_lane is not None:
+            with _on_stream(stream, dev):
+                torch.cuda.current_stream(dev).wait_event(self._side[stream][2])   # join in front of the fusion
+            lanes.append(tech_lane)
+        elif use_tech:
             lanes.append(self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
                                           stream=stream, verify=self.verify_tokens))
         lanes.append((d_ids, d_ct))
