@@ -87,6 +87,7 @@ class TechTokenIndex:
         self.tokens = torch.from_numpy(toks.view(np.int64)).to(device)
         self.ids = torch.from_numpy(ids).to(device)
         self._bitmaps: dict = {}   # per stream: two streams sharing one index must not share scratch
+        self._pinned: dict = {}    # per stream: ring of pinned upload buffers for the query tokens
         self._rank_of_id = None
         self._order_host, self._ids_host = order, ids
         self._row_tokens = [frozenset(t) for t in row_tokens] if verify else None
@@ -102,8 +103,25 @@ class TechTokenIndex:
             qn[i] = len(toks)
         words = max((self.n + 63) // 64, 1)
         with _on_stream(stream, self.device):
-            d_qt = torch.from_numpy(qt.view(np.int64)).to(self.device)
-            d_qn = torch.from_numpy(qn).to(self.device)
+            # uploads from a small ring of pinned buffers: a copy from pageable memory blocks the host until the
+            # stream has reached it, i.e. until the dense scan enqueued in front of it has finished -- host and GPU
+            # in lockstep, one step at a time
+            ring = self._pinned.setdefault(stream, {"next": 0, "slots": []})
+            if len(ring["slots"]) < 4:
+                ring["slots"].append((torch.empty(64, MAX_QUERY_TOKENS, dtype=torch.int64).pin_memory(),
+                                      torch.empty(64, dtype=torch.int32).pin_memory(), torch.cuda.Event()))
+            h_qt, h_qn, done = ring["slots"][ring["next"] % len(ring["slots"])]
+            ring["next"] += 1
+            if nq > 64:
+                raise ValueError("the exact-token lane takes at most 64 queries per call")
+            done.synchronize()          # the copy that last used this slot has left the host buffer
+            h_qt.numpy()[:nq] = qt.view(np.int64)
+            h_qn.numpy()[:nq] = qn
+            d_qt = torch.empty(nq, MAX_QUERY_TOKENS, dtype=torch.int64, device=self.device)
+            d_qn = torch.empty(nq, dtype=torch.int32, device=self.device)
+            d_qt.copy_(h_qt[:nq], non_blocking=True)
+            d_qn.copy_(h_qn[:nq], non_blocking=True)
+            done.record()
             bitmap = self._bitmaps.get(stream)
             if bitmap is None or bitmap.numel() < nq * words:
                 bitmap = self._bitmaps[stream] = torch.empty(nq * words, dtype=torch.int64, device=self.device)
@@ -204,14 +222,15 @@ class HybridSearcher:
     lane order bm25 -> tech_tokens -> dense."""
 
     def __init__(self, index, tech_index: "TechTokenIndex | None" = None, *, dense_k: int = 50, tech_k: int = 50,
-                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False, overlap_lanes: bool = True) -> None:
+                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False, overlap_lanes: bool = False) -> None:
         """verify_tokens: run the exact-token lane's host-side string check (a blocking D2H copy per step); off by
         default so that a step only enqueues work on the caller's stream.
-        overlap_lanes: the exact-token lane runs on a side stream BESIDE the dense scan (the two lanes are
-        independent until the fusion: retrieve.py:455-487 issues them one after the other only because SQL does);
-        its 28 bytes per row ride along with the scan's 2 KiB per row.  The side stream forks from the caller's
-        stream at the start of a call and joins it again in front of the fusion kernel, so to the caller a step is
-        still work enqueued on ITS stream."""
+        overlap_lanes: run the exact-token lane on a side stream beside the dense scan (forked from the caller's
+        stream behind the scan's launch, joined in front of the fusion kernel; same results, tested).  OFF by default:
+        measured on MI355X (1M chunks, 64 queries, dense top-100) 0.493-0.499 ms per step against 0.483 with the lanes
+        in series -- the scan holds every CU's whole register file (one 512-thread workgroup per CU), so the token
+        lane's workgroups only start when scan workgroups retire, and the fork / join events cost more than that
+        tail overlap returns."""
         self.index, self.tech = index, tech_index
         self.verify_tokens = bool(verify_tokens)
         self.overlap_lanes = bool(overlap_lanes)
@@ -238,7 +257,8 @@ class HybridSearcher:
         d_ids, d_sc, d_ct = self._dense_out[(stream, nq)]
         use_tech = self.tech is not None and query_token_lists is not None
         tech_lane = None
-        if use_tech and self.overlap_lanes and not self.verify_tokens:
+        overlap = use_tech and self.overlap_lanes and not self.verify_tokens
+        if overlap:
             # fork: everything the caller enqueued so far (queries, masks, the previous step's fusion, which may
             # still read the side stream's recycled buffers) is ordered before the side stream's work
             if stream not in self._side:
@@ -246,12 +266,13 @@ class HybridSearcher:
             side, fork, join = self._side[stream]
             with _on_stream(stream, dev):
                 fork.record()
+        self.index.search_async(query_vectors, self.dense_k, d_ids, d_sc, d_ct, d_row_mask=row_mask,
+                                mask_stride=mask_stride, stream=stream)
+        if overlap:  # the dense scan is enqueued first: the host's share of the token lane runs under it
             side.wait_event(fork)
             tech_lane = self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
                                          stream=side.cuda_stream, verify=False)
             join.record(side)
-        self.index.search_async(query_vectors, self.dense_k, d_ids, d_sc, d_ct, d_row_mask=row_mask,
-                                mask_stride=mask_stride, stream=stream)
         lanes = []
         if bm25 is not None:
             lanes.append(bm25)

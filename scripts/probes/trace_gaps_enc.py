@@ -9,8 +9,9 @@ from collections import defaultdict
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"].split("(")[0].replace("void ", ""))
-        tmpl = re.search(r"<([0-9, ]+)>", r["Kernel_Name"])
+        full = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).replace("void ", "")
+        tmpl = re.search(r"<([0-9, ]+)>", full)
+        name = re.split(r"[<(]", full)[0]
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name[:40] + (tmpl.group(0) if tmpl else "")))
 rows.sort()
 tail = rows[len(rows) // 2:]
