@@ -243,7 +243,10 @@ struct TechParams {
 
 __device__ __forceinline__ uint32_t tech_slot(uint64_t h) { return (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 52); }  // 12 bits
 
-__global__ __launch_bounds__(256) void tech_match_kernel(TechParams p) {
+// 1024 threads per block: the 64 KiB token table allows two blocks per CU, and with 256-thread blocks that was 8 waves
+// per CU -- two per SIMD for a kernel whose every step is a dependent load (row_ptr -> tokens -> LDS probe).
+constexpr int TECH_MATCH_THREADS = 1024;
+__global__ __launch_bounds__(TECH_MATCH_THREADS) void tech_match_kernel(TechParams p) {
     __shared__ unsigned long long s_key[TECH_SLOTS];   // 0 = empty (hash 0 is folded onto 1)
     __shared__ unsigned long long s_set[TECH_SLOTS];   // queries containing the token
     for (int i = threadIdx.x; i < TECH_SLOTS; i += blockDim.x) {
@@ -295,11 +298,24 @@ __global__ __launch_bounds__(256) void tech_match_kernel(TechParams p) {
         }
         unsigned long long mine = 0ull;
         if (__ballot(qset != 0ull) != 0ull) {  // wave-uniform: most 64-rank groups match no query at all
-            for (int q = 0; q < p.nq; ++q) {
-                bool hit = (qset >> q) & 1ull;
-                if (hit && p.mask) hit = (p.mask[(size_t)q * (size_t)p.mask_stride_w + (row >> 5)] >> (row & 31)) & 1u;
-                const unsigned long long b = __ballot(hit);
-                if (lane == q) mine = b;
+            // only the queries some row of the group matched get a ballot: the OR of the 64 sets, then a scalar walk
+            // over its bits (a group of 64 rows typically matches a handful of the 64 queries: 64 ballots per group
+            // were two thirds of this kernel's instructions)
+            unsigned long long any = qset;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) any |= (unsigned long long)__shfl_xor((long long)any, o);
+            uint32_t any_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)any);
+            uint32_t any_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(any >> 32));
+            for (int half = 0; half < 2; ++half) {
+                uint32_t bits = half ? any_hi : any_lo;
+                while (bits) {
+                    const int q = half * 32 + __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    bool hit = (qset >> q) & 1ull;
+                    if (hit && p.mask) hit = (p.mask[(size_t)q * (size_t)p.mask_stride_w + (row >> 5)] >> (row & 31)) & 1u;
+                    const unsigned long long b = __ballot(hit);
+                    if (lane == q) mine = b;
+                }
             }
         }
         if (lane < p.nq) p.bitmap[(size_t)(r0 >> 6) * p.nq + lane] = mine;
@@ -373,9 +389,9 @@ extern "C" int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, 
     p.out_ids = d_out_ids;
     p.out_counts = d_out_counts;
     if (p.words == 0) p.words = 1;
-    int64_t blocks = (p.words * 64 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;  // persistent blocks: the LDS token table is built once per block
-    hipLaunchKernelGGL(tech_match_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    int64_t blocks = (p.words * 64 + TECH_MATCH_THREADS - 1) / TECH_MATCH_THREADS;
+    if (blocks > 512) blocks = 512;  // persistent blocks (two per CU): the LDS token table is built once per block
+    hipLaunchKernelGGL(tech_match_kernel, dim3((unsigned)blocks), dim3(TECH_MATCH_THREADS), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(tech_select_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
