@@ -227,10 +227,10 @@ class HybridSearcher:
         default so that a step only enqueues work on the caller's stream.
         overlap_lanes: run the exact-token lane on a side stream beside the dense scan (forked from the caller's
         stream behind the scan's launch, joined in front of the fusion kernel; same results, tested).  OFF by default:
-        measured on MI355X (1M chunks, 64 queries, dense top-100) 0.493-0.499 ms per step against 0.483 with the lanes
-        in series -- the scan holds every CU's whole register file (one 512-thread workgroup per CU), so the token
-        lane's workgroups only start when scan workgroups retire, and the fork / join events cost more than that
-        tail overlap returns."""
+        measured on MI355X in alternating rounds (1M chunks, 64 queries, dense top-100) 0.440 ms per step against
+        0.441 with the lanes in series -- the scan holds every CU's whole register file (one 512-thread workgroup
+        per CU), so the token lane's workgroups only start when scan workgroups retire: nothing to win, and two
+        more events per step."""
         self.index, self.tech = index, tech_index
         self.verify_tokens = bool(verify_tokens)
         self.overlap_lanes = bool(overlap_lanes)
