@@ -623,6 +623,19 @@ def test_one_short_query_takes_the_five_launch_layer_and_matches_transformers(gp
         assert diff.pow(2).mean().sqrt() <= 6.5e-4 and diff.max() <= 3e-3, lens
         assert ((fast.cpu() * want).sum(-1)).min() >= 0.9998, lens
         assert (fast - eager).abs().max() <= 3e-3, lens
+    # mean pooling takes no graph, but 16 / 32 token rows still run the five-launch layer (its final RMSNorm + mean)
+    monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
+    monkeypatch.delenv("CRAG_ENC_NO_SKINNY", raising=False)
+    enc.cfg.pooling = "mean"
+    try:
+        for lens in ([16], [7, 9], [32]):
+            token_lists = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
+            got = enc.embed_token_lists(token_lists).cpu()
+            want = _hf_embed(model, cfg, token_lists, "mean")
+            diff = (got - want).abs()
+            assert diff.pow(2).mean().sqrt() <= 6.5e-4 and diff.max() <= 3e-3, (lens, diff.max())
+    finally:
+        enc.cfg.pooling = "last"
 
 
 def test_backfill_through_native_encoder_into_hbm_index(gpu, monkeypatch):
