@@ -276,9 +276,10 @@ struct alignas(16) Pack8s {
 };
 
 template <int QB>
-__global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnParams p) {
+__global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p) {
     constexpr int T = 16 * QB;
-    constexpr int ITEMS = 3 * QB;  // (token, q | k | v) head vectors per 16-lane group
+    constexpr int THREADS = 256 * QB, GROUPS = THREADS / 16;
+    constexpr int ITEMS = 3 * T / GROUPS;  // (token, q | k | v) head vectors per 16-lane group: three, for 16 and 32 rows
     __shared__ alignas(16) u16 Qs[T][136];
     __shared__ alignas(16) u16 Ks[T][136];
     __shared__ alignas(16) u16 Vt[CRAG_HEAD_DIM][40];  // [d][key slot in PV-fragment order], 32 slots + pad
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnParams p) {
     float cs[ITEMS][16];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const int it = grp + 16 * i, t = it / 3, which = it % 3;
+        const int it = grp + GROUPS * i, t = it / 3, which = it % 3;
         const int head = which == 0 ? h : (which == 1 ? p.hq + kvh : p.hq + p.hkv + kvh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[i].v[e] = 0;
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(256) void small_attn_kernel(SmallAttnParams p) {
     }
     const Pack8s wq8 = *reinterpret_cast<const Pack8s *>(p.qw + sub * 8);
     const Pack8s wk8 = *reinterpret_cast<const Pack8s *>(p.kw + sub * 8);
-    for (int i = threadIdx.x; i < CRAG_HEAD_DIM * 40 / 2; i += 256) reinterpret_cast<uint32_t *>(&Vt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < CRAG_HEAD_DIM * 40 / 2; i += THREADS) reinterpret_cast<uint32_t *>(&Vt[0][0])[i] = 0;
     if (threadIdx.x < T)
         start[threadIdx.x] = (int)threadIdx.x < p.n_tokens ? (int)threadIdx.x - p.positions[threadIdx.x] : -1 - (int)threadIdx.x;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-        const int it = grp + 16 * i, t = it / 3, which = it % 3;
+        const int it = grp + GROUPS * i, t = it / 3, which = it % 3;
         if (which == 2) {
             const int slot = 8 * ((t & 15) >> 2) + 4 * (t >> 4) + (t & 3);
 #pragma unroll
@@ -485,7 +486,7 @@ int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, cons
     p.eps = eps;
     p.scale_log2 = scale * 1.4426950408889634f;
     if (n_tokens <= 16) hipLaunchKernelGGL(small_attn_kernel<1>, dim3((unsigned)hq), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(small_attn_kernel<2>, dim3((unsigned)hq), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(small_attn_kernel<2>, dim3((unsigned)hq), dim3(512), 0, (hipStream_t)stream, p);
     return hip_ok("small_attention");
 }
 
