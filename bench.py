@@ -116,14 +116,16 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
         step()
     fence()
     index.prefilter_stats()
-    # Live HIP-event samples on the launch stream, SPARSE: a sampled search carries five extra event packets, and at
-    # the driver's --steps 20 sampling every search (round 2) stretched the timed step from 57 to 76 us.  At most
-    # every 8th search of the timed region is sampled; the same workload then continues untimed until 64 samples
-    # exist.
-    every = max(8, (steps * rounds) // 64)
+    # Live HIP-event samples on the launch stream, SPARSE: a sampled search carries five extra event packets = 19 us
+    # (scripts/probes/round_fixed_cost.py: a round of 20 searches takes 976 us without sampling, 1024 us with every
+    # 8th search sampled; at the driver's --steps 20, sampling EVERY search (round 2) stretched the timed step from
+    # 57 to 76 us).  At most every 20th search of the timed region is sampled (the one in the middle of its window of
+    # 20: one per round of the driver's form); the same workload then continues untimed until 64 samples exist.
+    every = max(20, (steps * rounds) // 64)
     index.profile_enable(every)
     times = timed_rounds(step, fence, steps, rounds)
-    in_region = (steps * rounds + every - 1) // every
+    total = steps * rounds                     # the library samples the searches c with c % every == every // 2
+    in_region = (total - every // 2 - 1) // every + 1 if total > every // 2 else 0
     for _ in range(max(0, 64 - in_region) * every):
         step()
     fence()

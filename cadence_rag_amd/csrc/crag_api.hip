@@ -235,7 +235,9 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                     (long long)ix->size);
 
     EvSet *ev = nullptr;
-    if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == 0) {
+    // (the sampled search is the one in the MIDDLE of every window of N: with a caller that synchronises every N searches
+    // the first of a window starts on an idle GPU and is not the typical one)
+    if (ix->profiling > 0 && (ix->prof_calls++ % ix->profiling) == ix->profiling / 2) {
         if (ix->ev_used == ix->ev_pool.size()) {
             EvSet t;
             HIP_TRY(hipEventCreate(&t.e0));
