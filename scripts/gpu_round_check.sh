@@ -29,7 +29,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $O/pmc_sq_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
+# one 16-token query through the 36 layers, graph replays: per-kernel durations of the five-launch layer
+rocprofv3 --kernel-trace --output-format csv -d $O/trace_small -- python3 $R/scripts/probes/small_encode_trace.py > $O/small_encode_trace.log 2>&1 || true
 cd $R
+f=$(find $O/trace_small -name "*kernel_trace.csv" | head -1)
+if [ -n "$f" ]; then ( grep tokens $O/small_encode_trace.log; python scripts/probes/trace_gaps_enc.py $f ) > $O/${RN}_small_layer_kernel_trace.txt 2>&1 || true; fi
 python scripts/pmc_summary.py stats $O/stats $O/${RN}_bench_kernel_stats.csv
 python scripts/pmc_summary.py stats $O/stats_headline $O/${RN}_headline_leg_kernel_stats.csv
 for w in 100k64 1m32 1m64; do
@@ -41,7 +45,7 @@ python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_100k64.csv $O/${RN
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m32.csv $O/${RN}_pmc_WRITE_SIZE_1m32.csv 1000000x32x10 $O/traffic.json
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m64.csv $O/${RN}_pmc_WRITE_SIZE_1m64.csv 1000000x64x10 $O/traffic.json
 # raw traces are large: keep only summaries
-rm -rf $O/pmc_* $O/stats $O/stats_headline
+rm -rf $O/pmc_* $O/stats $O/stats_headline $O/trace_small
 cp $O/bench.json $O/${RN}_bench_line.json; cp $O/bench_steps20.json $O/${RN}_bench_line_steps20.json; grep '^{' $O/bench_n2_gloo_rehearsal.json > $O/${RN}_bench_n2_gloo_rehearsal.json || true
 cat $O/traffic.json
 head -14 $O/${RN}_bench_kernel_stats.csv | cut -c1-160
