@@ -19,7 +19,8 @@
 //     of L2 reads, while its first 80 KB of weights are on their way from HBM) -- two launches per layer less;
 //   * the n-tile height R follows the chip: R rows of the weight per tile with R * tiles = N and tiles a multiple
 //     of the 256 CUs wherever N allows -- R = 10 for N = 2560 (o, down: 256 tiles, one per CU; with 16-row tiles
-//     160 workgroups streamed 304 KB each while 96 CUs idled), R = 12 for qkv (512 tiles), 16 for gate|up (1216);
+//     160 workgroups streamed 304 KB each while 96 CUs idled: the whole forward 2.53 vs 2.57 ms with 16-row tiles
+//     for down, 3.60 vs 3.68 ms at 32 rows), R = 12 for qkv (512 tiles), 16 for gate|up (1216);
 //     an MFMA still multiplies 16 rows, the lanes of the missing rows re-read the tile's last row (same cache
 //     line, no HBM bytes) and their results are dropped;
 //   * one resident workgroup per CU walks its tiles (tile, tile + grid, ...) with the weight ring running ONE TILE
