@@ -2088,6 +2088,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 //    the fmaf chain of v_mfma_f32_32x32x2_f32 in the kernels' k order, the 8 slice sums added in wave order,
 //    x (1/||row|| * 1/||q||), clamp -- so scores and order are bit-identical to the fp32 scan.
 // 3. rank by counting among the exact keys.
+// The bit search for the k-th approximate score stops FIN_SKIP_BITS above the bottom: the candidates that share the
+// remaining high bits with the answer (typically one to three of them) are ranked by counting instead -- four rounds
+// of a barrier + two wave reductions each become one.  The result is the EXACT k-th value, as before.
+constexpr int FIN_SKIP_BITS = 12;
 constexpr int FIN_ROUND = 4096;             // candidates examined per round (all of them, for k <= 128 on the bench's corpora)
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
@@ -2310,40 +2314,80 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
                 vmin = b < vmin ? b : vmin;
             }
             const uint32_t diff = vmax ^ vmin;
-            const int top = diff ? 32 - __builtin_clz(diff) : 0;       // bits [top, 32) are common to all candidates
+            const int top0 = diff ? 32 - __builtin_clz(diff) : 0;      // bits [top0, 32) are common to all candidates
+            const int top = top0 > FIN_SKIP_BITS ? top0 : FIN_SKIP_BITS;
             uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
-            // The answer only feeds a threshold 2 delta = 2.5e-3 below it, so its low FIN_SKIP_BITS bits stay zero
-            // (a LOWER value: at most 2^12 fp32 ulps = 2.4e-4 below the k-th score for |score| <= 1, a few percent
-            // more survivors, four rounds of this search less).
-            constexpr int FIN_SKIP_BITS = 12;
-            for (int bit = top, round = 0; bit > FIN_SKIP_BITS; ++round) {
-                const int nb = bit - FIN_SKIP_BITS >= 3 ? 3 : bit - FIN_SKIP_BITS, lo = bit - nb;  // this round decides bits [lo, bit)
-                // digit d of a candidate: 0 if below ans | (1 << lo), else min((v - ans) >> lo, 7); packed counters:
-                // a = #d==1 | #d==2 << 16 | #d==3 << 32 | #d==4 << 48, b = #d==5 | #d==6 << 16 | #d==7 << 32
-                unsigned long long a = 0ull, b = 0ull;
-                auto tally = [&](uint32_t x) {
-                    if (x >= ans) {
-                        const uint32_t d0 = (x - ans) >> lo;
-                        const uint32_t d = d0 > 7u ? 7u : d0;
-                        a += (d >= 1u && d <= 4u) ? 1ull << (16 * (d - 1u)) : 0ull;
-                        b += (d >= 5u) ? 1ull << (16 * (d - 5u)) : 0ull;
-                    }
-                };
-                if (in_lds) {
+            int round = 0;
+            auto search_bits = [&](int from_bit, int to_bit) {  // decides bits [to_bit, from_bit) of ans, three per round
+                for (int bit = from_bit; bit > to_bit; ++round) {
+                    const int nb = bit - to_bit >= 3 ? 3 : bit - to_bit, lo = bit - nb;  // this round decides bits [lo, bit)
+                    // digit d of a candidate: 0 if below ans | (1 << lo), else min((v - ans) >> lo, 7); packed counters:
+                    // a = #d==1 | #d==2 << 16 | #d==3 << 32 | #d==4 << 48, b = #d==5 | #d==6 << 16 | #d==7 << 32
+                    unsigned long long a = 0ull, b = 0ull;
+                    auto tally = [&](uint32_t x) {
+                        if (x >= ans) {
+                            const uint32_t d0 = (x - ans) >> lo;
+                            const uint32_t d = d0 > 7u ? 7u : d0;
+                            a += (d >= 1u && d <= 4u) ? 1ull << (16 * (d - 1u)) : 0ull;
+                            b += (d >= 5u) ? 1ull << (16 * (d - 5u)) : 0ull;
+                        }
+                    };
+                    if (in_lds) {
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) tally(v[i]);
-                } else {
-                    for (int e = tid; e < C; e += MERGE_THREADS) tally(gcand[e].x);
+                        for (int i = 0; i < PER; ++i) tally(v[i]);
+                    } else {
+                        for (int e = tid; e < C; e += MERGE_THREADS) tally(gcand[e].x);
+                    }
+                    block_sum2(a, b, round);
+                    int at_least = 0;  // candidates whose digit is >= j, j = 7 .. 1
+                    uint32_t pick = 0u;
+                    for (int j = 7; j >= 1; --j) {
+                        at_least += (int)(((j >= 5 ? b >> (16 * (j - 5)) : a >> (16 * (j - 1)))) & 0xffffull);
+                        if (pick == 0u && at_least >= k && j < (1 << nb)) pick = (uint32_t)j;
+                    }
+                    ans |= pick << lo;
+                    bit = lo;
                 }
-                block_sum2(a, b, round);
-                int at_least = 0;  // candidates whose digit is >= j, j = 7 .. 1
-                uint32_t pick = 0u;
-                for (int j = 7; j >= 1; --j) {
-                    at_least += (int)(((j >= 5 ? b >> (16 * (j - 5)) : a >> (16 * (j - 1)))) & 0xffffull);
-                    if (pick == 0u && at_least >= k && j < (1 << nb)) pick = (uint32_t)j;
+            };
+            search_bits(top, FIN_SKIP_BITS);
+            // ans = the k-th value with its low FIN_SKIP_BITS bits cleared: the k-th value itself is one of the
+            // candidates in [ans, ans + 2^FIN_SKIP_BITS).  Count what lies above that bucket, collect the bucket (in
+            // `surv`, free until step 2) and rank it by counting.
+            if (tid == 0) s_nsurv = 0;
+            __syncthreads();
+            const uint32_t hi = ans + (1u << FIN_SKIP_BITS);   // (scores <= 1: ord <= 0xbf800000, no wrap)
+            unsigned long long above = 0ull, unused = 0ull;
+            auto sift = [&](uint32_t x) {
+                if (x >= hi) {
+                    ++above;
+                } else if (x >= ans && x != 0u) {
+                    const int slot = atomicAdd(&s_nsurv, 1);
+                    if (slot < FIN_ROUND) surv[slot] = x;
                 }
-                ans |= pick << lo;
-                bit = lo;
+            };
+            if (in_lds) {
+#pragma unroll
+                for (int i = 0; i < PER; ++i) sift(v[i]);
+            } else {
+                for (int e = tid; e < C; e += MERGE_THREADS) sift(gcand[e].x);
+            }
+            block_sum2(above, unused, round++);   // (its barrier also publishes the bucket)
+            const int nbk = s_nsurv, need = k - (int)above;   // the bucket's need-th largest is the answer
+            __syncthreads();                                  // (everybody has read s_nsurv before it is reused)
+            if (nbk <= 2 * MERGE_THREADS && need >= 1 && need <= nbk) {
+                for (int e = tid; e < nbk; e += MERGE_THREADS) {
+                    const uint32_t mine = surv[e];
+                    int rank = 0;
+                    for (int i = 0; i < nbk; ++i) {
+                        const uint32_t o = surv[i];
+                        rank += (o > mine || (o == mine && i < e)) ? 1 : 0;
+                    }
+                    if (rank == need - 1) s_kth = mine;
+                }
+                __syncthreads();
+                ans = s_kth;
+            } else {
+                search_bits(FIN_SKIP_BITS, 0);   // thousands of candidates in one bucket (duplicated rows): finish bit by bit
             }
             if (tid == 0) s_kth = ans;
             __syncthreads();
