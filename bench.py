@@ -16,7 +16,7 @@ Workloads (BASELINE.json):
           the same 64 queries, one all-gather, merge.  Total work is fixed: "scaling": "strong"; the 1-GPU point
           of that curve is `target_1m.q64` of the N = 1 line.  `--mode weak` instead keeps 100 000 rows per rank.
 `value` is always DISTINCT queries answered per second by the whole job (never multiplied by the rank count).
-Rank 0 prints ONE JSON line.
+Rank 0 prints a `DETAIL {...}` line with every leg, then LAST the ONE compact JSON line (< 4 KB) the driver parses.
 """
 from __future__ import annotations
 
@@ -120,13 +120,14 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
     # (scripts/probes/round_fixed_cost.py: a round of 20 searches takes 976 us without sampling, 1024 us with every
     # 8th search sampled; at the driver's --steps 20, sampling EVERY search (round 2) stretched the timed step from
     # 57 to 76 us).  At most every 20th search of the timed region is sampled (the one in the middle of its window of
-    # 20: one per round of the driver's form); the same workload then continues untimed until 64 samples exist.
-    every = max(20, (steps * rounds) // 64)
+    # 20: one per round of the driver's form); the same workload then continues untimed until 64 (short runs: 24) samples exist.
+    total = steps * rounds                     # the library samples the searches c with c % every == every // 2
+    want = 64 if total >= 1000 else 24         # a short run (the driver's --steps 20) continues for 24 samples only
+    every = max(20, total // want)
     index.profile_enable(every)
     times = timed_rounds(step, fence, steps, rounds)
-    total = steps * rounds                     # the library samples the searches c with c % every == every // 2
     in_region = (total - every // 2 - 1) // every + 1 if total > every // 2 else 0
-    for _ in range(max(0, 64 - in_region) * every):
+    for _ in range(max(0, want - in_region) * every):
         step()
     fence()
     n_launch, scan_ms, rest_ms, pair_ms = index.profile_read_ex()
@@ -185,35 +186,24 @@ def roofline(rows, nq, k, leg, traffic_doc):
     q_pad = ((nq + 31) // 32) * 32
     per = max(leg["stats"]["searches"], 1)
     prefilter = "prefilter" in leg["kernel"]
+    mfma_tfs = 2.0 * q_pad * rows * DIM / scan_s / 1e12 if scan_s > 0 else 0.0
     out = {
         "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
-        "kernel": leg["kernel"], "kernel_avg_us": round(leg["scan_us"], 2),
+        "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": leg["kernel"].replace("crag::", ""), "kernel_avg_us": round(leg["scan_us"], 2),
+        # how kernel_avg_us is derived from the three event numbers: DESIGN.md 5
         "kernel_event_interval_us": round(leg.get("scan_raw_us", leg["scan_us"]), 2),
         "event_pair_overhead_us": round(leg.get("event_pair_us", 0.0), 2),
-        "timing": "HIP events on the launch stream around the scan launch; kernel_avg_us = that interval minus HALF "
-                  "the interval two back-to-back events measure with nothing between (recorded with every sample: "
-                  "one of the pair's two serialised event completions lies inside an interval around one kernel); "
-                  "rocprofv3 --kernel-trace durations of the same command: profiles/",
         "other_kernels_avg_us": round(leg["rest_us"], 2), "launches_timed": leg["n_launch"],
         "samples_in_timed_region": leg.get("samples_in_timed_region"),
         "algorithmic_bytes_per_launch": alg, "row_bytes_streamed": row_bytes,
-        "matrix_pipe": ("fp16 MFMA (v_mfma_f32_32x32x16_f16), %.1f TFLOP/s of the 2500 dense peak: not the bound"
-                        % (2.0 * q_pad * rows * DIM / scan_s / 1e12)) if prefilter else
-                       ("fp32 MFMA %.1f TFLOP/s = %.3f of %.1f" % (2.0 * q_pad * rows * DIM / scan_s / 1e12,
-                                                                    2.0 * q_pad * rows * DIM / scan_s / 1e12 / FP32_MFMA_PEAK_TFS,
-                                                                    FP32_MFMA_PEAK_TFS)),
+        "cache_assisted": bool(rows * row_bytes < 256 * 2**20),   # streamed bytes fit the 256 MiB Infinity Cache
+        "matrix_pipe_tflops": round(mfma_tfs, 1), "matrix_pipe": "fp16 MFMA" if prefilter else "fp32 MFMA",
     }
-    if row_bytes != DIM * 4:
+    if not prefilter:
+        out["matrix_pipe_frac"] = round(mfma_tfs / FP32_MFMA_PEAK_TFS, 3)
+    if row_bytes != DIM * 4:   # N*D*4 / the same time: what a scan of the fp32 rows would need; NOT a roofline quantity
         out["fp32_rows_equivalent_GBs"] = round(rows * DIM * 4 / scan_s / 1e9, 1) if scan_s > 0 else 0.0
-        out["note"] = ("the scan streams the fp16 mirror (D*2 bytes per row, + 50 % HBM footprint); "
-                       "fp32_rows_equivalent_GBs = N*D*4 / kernel time is what a scan of the fp32 rows would have to "
-                       "sustain for the same time -- not a roofline quantity")
-    if rows * row_bytes < 256 * 2**20:
-        out["cache_assisted"] = True
-        out["cache_note"] = ("the streamed bytes (%.0f MB) fit the 256 MiB Infinity Cache and consecutive passes "
-                             "alternate direction: part of this rate is served from that cache, not from HBM; the "
-                             "1M-row legs (target_1m) are the HBM-streaming measurement" % (rows * row_bytes / 1e6))
     if prefilter:  # declared separately: rows re-read for the exact fp32 score, 4 KiB each
         out["rescored_rows_per_launch"] = round(leg["stats"]["rescored_rows"] / per, 1)
         out["rescored_bytes_per_launch"] = int(leg["stats"]["rescored_rows"] / per * DIM * 4)
@@ -221,10 +211,9 @@ def roofline(rows, nq, k, leg, traffic_doc):
     key = f"{rows}x{nq}x{k}"
     if traffic_doc and key in traffic_doc.get("by_workload", {}):
         t = traffic_doc["by_workload"][key]
-        if t.get("kernel", "").split("(")[0].replace("void ", "") == leg["kernel"]:
-            out["traffic"] = t["hbm_bytes_per_launch"]
-            out["traffic_source"] = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in " \
-                                    "separate earlier runs (FETCH x2 per the gfx950 note), not measured in this run"
+        if t.get("kernel", "").split("(")[0].replace("void ", "").replace("crag::", "") == out["kernel"]:
+            out["traffic"] = t["hbm_bytes_per_launch"]   # separate rocprofv3 --pmc passes, not this run
+            out["traffic_source"] = "profiles/traffic.json"
     return out
 
 
@@ -382,11 +371,9 @@ def encode_leg(dev, rank: int, world: int, dist, steps: int, enc=None):
         # per GPU: `tflops` is this rank's own batch over the slowest rank's time
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": round(tflops / 2500.0, 4), "traffic": None,
-                     "executed_tflops": round(tflops_exec, 1), "executed_frac": round(tflops_exec / 2500.0, 4),
-                     "note": "per GPU; whole forward (library GEMMs + HIP ops); achieved = SURVEY 8(d)'s algorithmic "
-                             "FLOPs (2*P + causal attention per token of the model) / time; executed_* leaves out "
-                             "the last layer's o / MLP projections of the non-pooled rows, which last-token pooling "
-                             "never needs and the forward does not compute"},
+                     # per GPU; achieved = SURVEY 8(d)'s algorithmic FLOPs (2*P + causal attention per token) / time;
+                     # executed_* leaves out the last layer's o / MLP projections of the non-pooled rows
+                     "executed_tflops": round(tflops_exec, 1), "executed_frac": round(tflops_exec / 2500.0, 4)},
     }
     if rank == 0:
         try:
@@ -498,9 +485,8 @@ def hybrid_leg(big_index, rows: int, dev, k_dense: int = 100, k_tech: int = 50, 
     return {"workload": f"BASELINE configs[4]: hybrid retrieve, {rows} chunks, batch {nq}: dense top-{k_dense} + "
                         f"exact-token lane top-{k_tech} + given BM25 ranks (50) -> RRF on the GPU",
             "ms_per_step": round(dt * 1e3, 4), "value": round(nq / dt, 1), "unit": "queries/sec", "steps": steps,
-            "rounds": "median of 3 rounds of `steps` steps, alternating with the side-stream variant, after 30 warm steps",
-            "lanes": "in series on the caller's stream (query tokens uploaded from a pinned ring: the host never "
-                     "waits for the scan)",
+            # median of 3 rounds of `steps` steps, alternating with the side-stream variant, after 30 warm steps; lanes in
+            # series on the caller's stream
             "ms_per_step_token_lane_on_side_stream": round(dt_side * 1e3, 4), "results_identical_on_side_stream": same,
             "split": split, "fused_counts_min": int(cnt.min()), "self_check_ok": ok,
             "dense_roofline": roofline(rows, nq, k_dense, dense_leg, None)}
@@ -579,9 +565,8 @@ def query_path_leg(enc, cfg, big_index, big, dev, dev_index, query_tokens: int =
                 "encode_ms": round(e_lat * 1e3, 4),
                 "encode_ms_eager_launches": round(eager_lat * 1e3, 4),
                 "encode_roofline": {"bound": "hbm", "achieved": round(weight_bytes / e_lat / 1e9, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(weight_bytes / e_lat / 1e9 / HBM_PEAK_GBS, 4),
-                                    "note": "algorithmic bytes = the 36 layers' bf16 weights, read once per forward "
-                                            "(activations of %d tokens are noise beside them)" % (nq * query_tokens)},
+                                    # algorithmic bytes = the 36 layers' bf16 weights, read once per forward
+                                    "unit": "GB/s", "frac": round(weight_bytes / e_lat / 1e9 / HBM_PEAK_GBS, 4)},
                 "search_chunks_k50": {"ms_per_step": round(chunks_leg["times"][0] / 60 * 1e3, 4),
                                       "roofline": roofline(ROWS_CONFIG2, nq, 50, chunks_leg, None)},
                 "search_artifacts_k10": {"ms_per_step": round(art_leg["times"][0] / 100 * 1e3, 4),
@@ -593,6 +578,96 @@ def query_path_leg(enc, cfg, big_index, big, dev, dev_index, query_tokens: int =
     finally:
         art.close()
     return out
+
+
+COMPACT_LIMIT = 4096   # the driver keeps 8 KB of stdout: the LAST line must fit with room to spare
+
+
+def _get(d, *path, default=None):
+    for key in path:
+        if not isinstance(d, dict) or key not in d:
+            return default
+        d = d[key]
+    return d
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE line the driver parses (the bench contract's keys, `roofline`, `cpu_baseline`, and one number per
+    secondary leg).  Everything else is in the DETAIL line printed before it and in gpurun_out/bench_detail.json."""
+    cfg = full.get("config", {})
+    roof = full.get("roofline", {})
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": cfg.get("workload"), "rows": cfg.get("rows_total"), "k": cfg.get("k"),
+                     "queries_per_step": cfg.get("queries_per_step"), "parallelism": cfg.get("parallelism"),
+                     "arithmetic": cfg.get("arithmetic"),
+                     "recall": cfg.get("recall_at_10_vs_fp64_oracle"),
+                     "order_identical": cfg.get("topk_order_identical_to_oracle"),
+                     "ms_per_step_median": cfg.get("ms_per_step_median")}
+    for key in ("api", "ms_per_step_in_order_api"):
+        if key in cfg:
+            out["config"][key] = cfg[key]
+    if cfg.get("per_rank_step_breakdown"):
+        rows_ = cfg["per_rank_step_breakdown"]
+        out["config"]["per_rank_us_max"] = {f: max(r.get(f, 0) for r in rows_ if r) for f in
+                                            ("search_us", "exchange_us", "merge_us", "scan_kernel_us")}
+        out["config"]["speedup_vs_same_job_on_one_gpu"] = cfg.get("speedup_vs_same_job_on_one_gpu")
+        out["config"]["scaling_curve_measured"] = cfg.get("scaling_curve_measured")
+    out["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                "kernel_avg_us", "cache_assisted", "samples_in_timed_region",
+                                                "launches_timed", "algorithmic_bytes_per_launch")}
+    base = full.get("cpu_baseline")
+    if base is not None:
+        out["cpu_baseline"] = {k: base.get(k) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value")}
+        out["cpu_baseline"]["encode_chunks_per_s"] = _get(base, "encode", "value")
+    summ = {
+        "streams2_q_per_s": _get(cfg, "steps_overlapped_on_streams", "2", "value"),
+        "fp32_rows_scan_frac": _get(full, "fp32_rows_scan", "roofline", "frac"),
+        "target_1m_q32_frac": _get(full, "target_1m", "q32", "roofline", "frac"),
+        "target_1m_q64_frac": _get(full, "target_1m", "q64", "roofline", "frac"),
+        "target_1m_q64_kernel_us": _get(full, "target_1m", "q64", "roofline", "kernel_avg_us"),
+        "target_1m_q64_ms": _get(full, "target_1m", "q64", "ms_per_step"),
+        "target_1m_q64_q_per_s": _get(full, "target_1m", "q64", "value"),
+        "target_1m_q64_recall": _get(full, "target_1m", "q64", "recall_at_10_vs_fp64_oracle"),
+        "target_1m_q64_fp32_rows_frac": _get(full, "target_1m", "q64", "fp32_rows_scan", "roofline", "frac"),
+        "hybrid_ms": _get(full, "hybrid", "ms_per_step"),
+        "hybrid_dense_frac": _get(full, "hybrid", "dense_roofline", "frac"),
+        "hybrid_token_lane_us": _get(full, "hybrid", "split", "token_lane_top50_us"),
+        "k100_100k_ms": _get(full, "large_k", "100000x64x100", "ms_per_step"),
+        "k100_100k_frac": _get(full, "large_k", "100000x64x100", "roofline", "frac"),
+        "nq1_encode_ms": _get(full, "query_path", "nq1", "encode_ms"),
+        "nq1_encode_frac": _get(full, "query_path", "nq1", "encode_roofline", "frac"),
+        "nq1_request_ms": _get(full, "query_path", "nq1", "request_latency_ms"),
+        "nq8_encode_ms": _get(full, "query_path", "nq8", "encode_ms"),
+        "nq8_encode_frac": _get(full, "query_path", "nq8", "encode_roofline", "frac"),
+        "nq64_encode_ms": _get(full, "query_path", "nq64", "encode_ms"),
+        "encode_chunks_per_s": _get(full, "encode", "value"),
+        "encode_frac": _get(full, "encode", "roofline", "frac"),
+        "backfill_chunks_per_s": _get(full, "encode", "backfill_path", "device_resident", "chunks_per_s"),
+    }
+    out["summary"] = {k: v for k, v in summ.items() if v is not None}
+    errs = [name for name in ("hybrid", "query_path", "encode", "target_1m") if _get(full, name, "error")]
+    if errs:
+        out["leg_errors"] = errs
+    out["detail"] = "DETAIL line above; gpurun_out/bench_detail.json"
+    text = json.dumps(out)
+    if len(text) >= COMPACT_LIMIT:   # never let a long workload string push the contract keys out of the record
+        out["config"]["workload"] = str(out["config"]["workload"])[:160]
+        out.pop("summary", None)
+    return out
+
+
+def emit(full: dict) -> None:
+    """DETAIL first (every leg, one line, prefixed so that no parser takes it for the bench line; also written to
+    gpurun_out/bench_detail.json), then the compact line LAST."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
+            json.dump(full, fh)
+    except OSError:
+        pass
+    print("DETAIL " + json.dumps(full), flush=True)
+    print(json.dumps(compact_line(full)), flush=True)
 
 
 def main() -> None:
@@ -824,21 +899,21 @@ def main() -> None:
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "strong" if mode == "strong" else "weak",
-            "vs_baseline": None, "dtype": "f32 (fp16 MFMA prefilter with a proven bound, exact fp32 rescoring)",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": workload,
                 "rows_per_gpu": rows, "rows_total": rows_total, "dim": DIM, "k": k, "queries_per_step": nq,
                 "parallelism": "1 GPU" if world == 1 else f"corpus sharded x{world}, all-gather top-k merge",
-                "value_counts": "distinct queries answered per second by the whole job (not multiplied by ranks)",
+                # `value` = distinct queries answered per second by the whole job (never multiplied by the rank count)
                 "rounds": args.rounds,
                 "ms_per_step_rounds": [round(t / args.steps * 1e3, 5) for t in times],
                 "ms_per_step_median": round(statistics.median(times) / args.steps * 1e3, 5),
                 "ms_per_step_min": round(min(times) / args.steps * 1e3, 5),
                 "row_queries_per_s": round(rows_total * nq * args.steps / elapsed, 1),
-                "arithmetic": "fp16 MFMA prefilter over the fp16 mirror of the unit rows (2 KiB per row beside the "
-                              "4 KiB fp32 row) with a proven error bound + exact fp32 rescoring of the survivors "
-                              "from the fp32 rows: results bit-identical to the fp32 scan (DESIGN.md 4)",
+                # fp16 MFMA prefilter over the fp16 mirror with a proven bound + exact fp32 rescoring from the fp32 rows:
+                # results bit-identical to the fp32 scan
+                "arithmetic": "fp16-MFMA prefilter (proven bound) + exact fp32 rescoring",
                 "hbm_bytes_per_corpus_row": DIM * 4 + (leg.get("row_bytes") if leg.get("row_bytes") != DIM * 4 else 0) + 12,
             },
             "roofline": roof,
@@ -850,11 +925,9 @@ def main() -> None:
                 if "value" in same_job_1gpu:
                     line["config"]["speedup_vs_same_job_on_one_gpu"] = round(
                         nq * args.steps / elapsed / same_job_1gpu["value"], 3)
-            line["config"]["scaling_reference"] = (
-                "strong scaling of the fixed 1M-row job: its 1-GPU point is `config.same_job_on_one_gpu` (measured in "
-                "this run on rank 0) = `target_1m.q64` of the N = 1 line; the N = 1 `value` itself is configs[1], a "
-                "100 000-row corpus" if mode == "strong" else
-                "weak scaling: the corpus grows with N, so a flat `value` is ideal; compare `row_queries_per_s`")
+            # strong: the 1-GPU point of the fixed 1M-row job is config.same_job_on_one_gpu (= target_1m.q64 of the N = 1
+            # line; the N = 1 `value` itself is configs[1], 100 000 rows); weak: a flat `value` is ideal
+            line["config"]["scaling_curve_measured"] = "this line is one point; no curve without a multi-GPU node"
         if overlap is not None:
             line["config"]["steps_overlapped_on_streams"] = overlap
         if fp32_leg is not None:
@@ -877,7 +950,7 @@ def main() -> None:
             line["cpu_baseline"] = base
             line["config"]["recall_at_10_vs_fp64_oracle"] = recall
             line["config"]["topk_order_identical_to_oracle"] = same_order
-        print(json.dumps(line), flush=True)
+        emit(line)
 
     if world > 1:
         dist.barrier()
