@@ -101,6 +101,10 @@ struct crag_index {
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
         uint32_t seq = 0;            // sequence number of the last prefilter search on this workspace (never 0 in use)
         bool done_recorded = false;  // ... once a second stream has appeared (single-stream callers pay no event)
+        // a search failed between its scan launch and its selection launch: the per-query state the selection kernel
+        // leaves zeroed (class maxima, candidate counts, tickets) may hold the failed search's values -- the next search
+        // on this workspace re-zeroes it first
+        bool dirty = false;
         uint64_t last_use = 0;
     } ws[MAX_WS];
     uint64_t use_clock = 0;
@@ -119,6 +123,8 @@ struct crag_index {
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
     int pass_parity = 0;  // alternate scan direction between searches (Infinity Cache reuse)
+    int64_t env_fail_after_scan = 0;  // CRAG_TEST_FAIL_AFTER_SCAN=n (tests): the n-th prefilter search returns CRAG_EHIP
+    int64_t pf_searches = 0;          // between its scan launch and its selection launch
     int profiling = 0;      // 0 = off, N = record HIP events around every N-th search
     int64_t prof_calls = 0;
     std::vector<EvSet> ev_pool;
@@ -181,7 +187,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         // stream wait for the last search that used it (its owner may even be gone by now)
         for (auto &w : ix->ws)
             if (!ws || w.last_use < ws->last_use) ws = &w;
-        if (ws->done_recorded) {
+        if (ws->done_recorded && !ws->dirty) {   // (a failed search recorded no event)
             HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
         } else {
             // its last search predates the second stream (no event was recorded then): wait for the device
@@ -203,6 +209,11 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     // candidates per query; a fuller list sends the search to the exact fallback.  k > 104 (k_s = 27 .. 32 of a set's
     // 32 class maxima: a weak bound) passes several thousand rows per query on a 1M-row corpus
     const int cap = (k > 104 && nq_pad <= 128) ? 32768 : 8192;
+    // large k: several selection blocks per query share the exact rescoring (see finalize_fb_kernel)
+    const int rsplit = (k <= 32 || ix->env_no_rsplit) ? 1 : (nq <= 16 ? 8 : (nq <= 128 ? 4 : 1));
+    // Every allocation and memset of the search happens HERE, in front of its first launch: an allocation that fails
+    // between the scan and the selection launch would leave the scan's per-query state behind (and a hipFree /
+    // hipMalloc between two launches synchronises the device).
     if (prefilter) {
         if ((rc = ws->a16.ensure((size_t)nq_pad * crag::DIM * 2))) return rc;
         {   // n_cu idle records of zeros that nothing ever writes (zeroed once, when the buffer is allocated; at the
@@ -215,6 +226,17 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
             }
         }
         if ((rc = ws->pf_cand.ensure((size_t)nq_pad * cap * sizeof(uint2)))) return rc;
+        if (rsplit > 1) {   // scratch of the selection blocks that share a query (k > 32)
+            const size_t slots = (size_t)nq_pad * 8;
+            if ((rc = ws->pf_xkeys.ensure(slots * CRAG_MAX_K * sizeof(uint64_t)))) return rc;
+            if ((rc = ws->pf_xids.ensure(slots * CRAG_MAX_K * sizeof(int64_t)))) return rc;
+            if ((rc = ws->pf_xcount.ensure(slots * sizeof(uint2)))) return rc;
+            const size_t tneed = (size_t)nq_pad * sizeof(uint32_t);
+            if (tneed > ws->pf_xticket.bytes) {
+                if ((rc = ws->pf_xticket.ensure(tneed))) return rc;
+                HIP_TRY(hipMemsetAsync(ws->pf_xticket.p, 0, ws->pf_xticket.bytes, st));
+            }
+        }
         {   // per-query candidate counts and the overflow / ticket words: zero when allocated, kept clean by the kernels
             const size_t need = (size_t)nq_pad * sizeof(uint32_t);
             if (need > ws->pf_count.bytes) {
@@ -225,6 +247,13 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
                 if ((rc = ws->pf_flags.ensure(4 * sizeof(uint32_t)))) return rc;
                 HIP_TRY(hipMemsetAsync(ws->pf_flags.p, 0, ws->pf_flags.bytes, st));
             }
+        }
+        if (ws->dirty) {  // the last search on this workspace died between scan and selection: nothing cleaned up
+            HIP_TRY(hipMemsetAsync(ws->pf_gbound.p, 0, ws->pf_gbound.bytes, st));
+            HIP_TRY(hipMemsetAsync(ws->pf_count.p, 0, ws->pf_count.bytes, st));
+            HIP_TRY(hipMemsetAsync(ws->pf_flags.p, 0, ws->pf_flags.bytes, st));
+            if (ws->pf_xticket.p) HIP_TRY(hipMemsetAsync(ws->pf_xticket.p, 0, ws->pf_xticket.bytes, st));
+            ws->dirty = false;
         }
     }
 
@@ -335,7 +364,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
             fp.nt = !ix->corpus16 ? 0 : (ix->env_pf_nt >= 0 ? ix->env_pf_nt : (streamed > ix->nt_above_bytes ? 1 : 0));
         }
         const int nqb = wide ? 2 : 1;
+        ws->dirty = true;   // until the selection launch is in the stream
         HIP_TRY(crag::launch_prefilter(fp, nqb, nq_pad / (32 * nqb), st, &ix->last_scan_kernel));
+        if (ix->env_fail_after_scan > 0 && ++ix->pf_searches == ix->env_fail_after_scan)
+            return fail(CRAG_EHIP, "injected failure behind the scan launch (CRAG_TEST_FAIL_AFTER_SCAN)");
         if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
         crag::FinParams fin;
         fin.corpus = ix->corpus;
@@ -351,27 +383,20 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fin.out_ids = d_out_ids;
         fin.out_scores = d_out_scores;
         fin.out_counts = d_out_counts;
-        fin.stats = ix->pf_stats;
+        // statistics records: one block of PF_STAT_SLOTS / MAX_WS records per workspace, so that searches overlapping
+        // on several streams never share a record (queries beyond a block's size fold onto it: counts may be lost
+        // there, results never depend on them)
+        fin.stats = ix->pf_stats + (size_t)(ws - ix->ws) * (crag::PF_STAT_SLOTS / crag_index::MAX_WS) * 3;
         fin.k = k;
         fin.cap = cap;
         fin.merge = mp;
         fin.nq = nq;
-        // large k: several selection blocks per query share the exact rescoring (see finalize_fb_kernel)
-        fin.rsplit = (k <= 32 || ix->env_no_rsplit) ? 1 : (nq <= 16 ? 8 : (nq <= 128 ? 4 : 1));
+        fin.rsplit = rsplit;
         fin.xkeys = nullptr;
         fin.xids = nullptr;
         fin.xcount = nullptr;
         fin.xticket = nullptr;
         if (fin.rsplit > 1) {
-            const size_t slots = (size_t)nq_pad * 8;
-            if ((rc = ws->pf_xkeys.ensure(slots * CRAG_MAX_K * sizeof(uint64_t)))) return rc;
-            if ((rc = ws->pf_xids.ensure(slots * CRAG_MAX_K * sizeof(int64_t)))) return rc;
-            if ((rc = ws->pf_xcount.ensure(slots * sizeof(uint2)))) return rc;
-            const size_t tneed = (size_t)nq_pad * sizeof(uint32_t);
-            if (tneed > ws->pf_xticket.bytes) {
-                if ((rc = ws->pf_xticket.ensure(tneed))) return rc;
-                HIP_TRY(hipMemsetAsync(ws->pf_xticket.p, 0, ws->pf_xticket.bytes, st));
-            }
             fin.xkeys = (uint64_t *)ws->pf_xkeys.p;
             fin.xids = (int64_t *)ws->pf_xids.p;
             fin.xcount = (uint2 *)ws->pf_xcount.p;
@@ -386,6 +411,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fin.fb_blocks = G * ((nq + 31) / 32);
         fin.fb_done = (uint32_t *)ws->pf_flags.p + 1;
         HIP_TRY(crag::launch_finalize(fin, st));
+        ws->dirty = false;
     } else {
         HIP_TRY(crag::launch_scan(sp, q_blocks, st, &ix->last_scan_kernel));
         if (ev) HIP_TRY(hipEventRecord(ev->e2, st));
@@ -489,6 +515,7 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
     ix->env_no_rsplit = getenv("CRAG_NO_RSPLIT") != nullptr;  // developer switch: one selection block per query for any k
     if (const char *v = getenv("CRAG_PF_NT")) ix->env_pf_nt = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("CRAG_TEST_FAIL_AFTER_SCAN")) ix->env_fail_after_scan = atoll(v);
     if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
         // + 2 KiB per row beside the 4 KiB fp32 row: the prefilter scan then streams half the bytes.  Padding rows

@@ -100,7 +100,7 @@ struct FinParams {
     int64_t *out_ids;
     float *out_scores;
     int32_t *out_counts;
-    unsigned long long *stats;  // nullable; PF_STAT_SLOTS records {candidates, rescored rows, searches}, record q % SLOTS
+    unsigned long long *stats;  // nullable; the workspace's PF_STAT_SLOTS / 4 records {candidates, rescored rows, searches}
     int k, cap;
     int nq;                     // selection blocks of the launch: [0, nq * rsplit)
     int rsplit;                 // selection blocks per query (R)

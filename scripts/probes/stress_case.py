@@ -6,24 +6,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 import oracle
 from cadence_rag_amd.dense_index import DenseIndex
+from helpers import random_search_case
 
 seed, target = int(os.environ.get("SEED", 7)), int(os.environ.get("CASE", 78))
 rng = np.random.default_rng(seed)
 for case in range(target + 1):
-    n = int(rng.choice([1, 31, 33, 200, 777, 2500, 6000, 20000, 40000, 66000]))
-    nq = int(rng.integers(1, 71))
-    k = int(rng.choice([1, 5, 10, 31, 32, 33, 50, 64, 65, 100, 128]))
-    dim = int(rng.choice([1024, 1024, 1024, 1024, 260, 7]))
-    mask_p = rng.choice([-1, -1, 0.0, 0.01, 0.3, 1.0])
-    corpus = rng.standard_normal((n, dim)).astype(np.float32)
-    if n > 10:
-        corpus[n - 1] = corpus[2]
-        if rng.random() < 0.3:
-            corpus[rng.integers(0, n, size=3)] = 0.0
-        if rng.random() < 0.2:
-            corpus[5:9] = corpus[5]
-    q = rng.standard_normal((nq, dim)).astype(np.float32)
-    mask = None if mask_p < 0 else (rng.random((nq, n)) < mask_p)
+    c = random_search_case(rng)
+n, nq, k, dim, mask_p, corpus, q, mask = (c[x] for x in ("n", "nq", "k", "dim", "mask_p", "corpus", "queries", "mask"))
 print(f"case {target}: n={n} nq={nq} k={k} dim={dim} mask={mask_p}")
 ix = DenseIndex(dim, capacity=n)
 ix.add(corpus)

@@ -64,3 +64,39 @@ def cpu_merge_topk(g_ids, g_sc, g_ct):
             out_ids[q, j] = i
             out_sc[q, j] = -ns
     return out_ids, out_sc, out_ct
+
+
+def random_search_case(rng):
+    """One random search case of the stress run (tests/stress_search.py, scripts/probes/stress_case.py and the slice of
+    it that -m gpu carries): shapes around the kernels' switch points, duplicates, zero rows, per-query masks.
+    The draw order is part of the contract: (SEED, CASE) of a failure replays it."""
+    n = int(rng.choice([1, 31, 33, 200, 777, 2500, 6000, 20000, 40000, 66000]))  # the last two: prefilter path
+    nq = int(rng.integers(1, 71))
+    k = int(rng.choice([1, 5, 10, 31, 32, 33, 50, 64, 65, 100, 128]))
+    dim = int(rng.choice([1024, 1024, 1024, 1024, 260, 7]))
+    mask_p = rng.choice([-1, -1, 0.0, 0.01, 0.3, 1.0])
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    if n > 10:
+        corpus[n - 1] = corpus[2]
+        if rng.random() < 0.3:
+            corpus[rng.integers(0, n, size=3)] = 0.0
+        if rng.random() < 0.2:
+            corpus[5:9] = corpus[5]
+    q = rng.standard_normal((nq, dim)).astype(np.float32)
+    mask = None if mask_p < 0 else (rng.random((nq, n)) < mask_p)
+    return {"n": n, "nq": nq, "k": k, "dim": dim, "mask_p": float(mask_p), "corpus": corpus, "queries": q, "mask": mask}
+
+
+def random_short_token_lists(rng, vocab_size, shapes=("1x16", "1x32", "2x16")):
+    """One case of tests/stress_small_encode.py: token lists whose padded shape is one of the small-graph shapes."""
+    shape = rng.choice(list(shapes))
+    if shape == "1x16":
+        lens = [int(rng.integers(1, 17))]
+    elif shape == "1x32":
+        lens = [int(rng.integers(17, 33))]
+    elif shape == "2x16":
+        lens = [int(rng.integers(1, 17)), int(rng.integers(1, 17))]
+    else:   # "BxL": B sequences of up to L tokens (at least one reaches the bucket)
+        b, l = (int(x) for x in shape.split("x"))
+        lens = [int(rng.integers(max(1, l // 2 + 1), l + 1))] + [int(rng.integers(1, l + 1)) for _ in range(b - 1)]
+    return lens, [rng.integers(0, vocab_size, size=n).tolist() for n in lens]

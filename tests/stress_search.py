@@ -5,27 +5,15 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle
 from cadence_rag_amd.dense_index import DenseIndex
-from helpers import assert_topk_matches
+from helpers import assert_topk_matches, random_search_case
 
 n_cases = int(os.environ.get("CASES", 300))
 rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
 t0 = time.time()
 fails = 0
 for case in range(n_cases):
-    n = int(rng.choice([1, 31, 33, 200, 777, 2500, 6000, 20000, 40000, 66000]))  # the last two: prefilter path
-    nq = int(rng.integers(1, 71))
-    k = int(rng.choice([1, 5, 10, 31, 32, 33, 50, 64, 65, 100, 128]))
-    dim = int(rng.choice([1024, 1024, 1024, 1024, 260, 7]))
-    mask_p = rng.choice([-1, -1, 0.0, 0.01, 0.3, 1.0])
-    corpus = rng.standard_normal((n, dim)).astype(np.float32)
-    if n > 10:
-        corpus[n - 1] = corpus[2]
-        if rng.random() < 0.3:
-            corpus[rng.integers(0, n, size=3)] = 0.0
-        if rng.random() < 0.2:
-            corpus[5:9] = corpus[5]
-    q = rng.standard_normal((nq, dim)).astype(np.float32)
-    mask = None if mask_p < 0 else (rng.random((nq, n)) < mask_p)
+    c = random_search_case(rng)
+    n, nq, k, dim, mask_p, corpus, q, mask = (c[x] for x in ("n", "nq", "k", "dim", "mask_p", "corpus", "queries", "mask"))
     ix = DenseIndex(dim, capacity=n)
     try:
         ix.add(corpus)

@@ -5,7 +5,9 @@ import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from cadence_rag_amd.encoder.qwen3 import Qwen3Config, Qwen3Encoder
+from helpers import random_short_token_lists
 
 n_cases = int(os.environ.get("CASES", 300))
 rng = np.random.default_rng(int(os.environ.get("SEED", 3)))
@@ -14,14 +16,7 @@ cfg = Qwen3Config(num_layers=4, vocab_size=4096)
 enc = Qwen3Encoder.random_init(cfg, seed=11, device=dev)
 worst, fails, t0 = 0.0, 0, time.time()
 for case in range(n_cases):
-    shape = rng.choice(["1x16", "1x32", "2x16"])
-    if shape == "1x16":
-        lens = [int(rng.integers(1, 17))]
-    elif shape == "1x32":
-        lens = [int(rng.integers(17, 33))]
-    else:
-        lens = [int(rng.integers(1, 17)), int(rng.integers(1, 17))]
-    toks = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
+    lens, toks = random_short_token_lists(rng, cfg.vocab_size)
     os.environ.pop("CRAG_ENC_NO_GRAPH", None); os.environ.pop("CRAG_ENC_NO_SKINNY", None)
     fast = enc.embed_token_lists(toks)
     again = enc.embed_token_lists(toks)

@@ -270,6 +270,40 @@ def test_workspace_state_is_left_clean_by_every_kind_of_search(gpu, monkeypatch)
     assert_topk_matches(got[3][0][:2], got[3][1][:2], got[3][2][:2], *want, tol=TOL)
 
 
+@pytest.mark.parametrize("k", [10, 100])
+def test_a_search_that_fails_behind_its_scan_launch_leaves_no_stale_state(gpu, monkeypatch, k):
+    """the selection kernel is what leaves a query's class maxima and candidate count zeroed, so a search
+    that dies between its scan launch and its selection launch (an allocation failure, a launch error) leaves the
+    scan's state in the workspace.  CRAG_TEST_FAIL_AFTER_SCAN=2 makes the second search return an error right
+    there; its queries are copies of corpus rows (class maxima at 1.0), the next search's queries are random (best
+    scores ~0.15): with stale maxima every true neighbour of the third search would be discarded.  The library marks
+    the workspace dirty and re-zeroes it in front of the next search."""
+    from cadence_rag_amd._native import NativeLibraryError as NativeError
+    rng = np.random.default_rng(77)
+    n = 48_000
+    corpus = unit_rows(rng, n)
+    q_plain = rng.standard_normal((64, 1024)).astype(np.float32)
+    q_hot = corpus[rng.integers(0, n, size=64)].copy()
+    monkeypatch.setenv("CRAG_TEST_FAIL_AFTER_SCAN", "2")
+    ix = _index(corpus, monkeypatch)
+    monkeypatch.delenv("CRAG_TEST_FAIL_AFTER_SCAN")
+    try:
+        first = ix.search(q_plain, k)
+        assert "prefilter" in ix.last_scan_kernel()
+        with pytest.raises(NativeError, match="injected failure"):
+            ix.search(q_hot, k)
+        third = ix.search(q_plain, k)
+        fourth = ix.search(q_hot[:9], k)
+    finally:
+        ix.close()
+    for a, b in zip(first, third):
+        assert np.array_equal(a, b, equal_nan=True)
+    want = oracle.exact_topk(q_plain[:4], corpus, k, mode=oracle.F64, fast=True)
+    assert_topk_matches(third[0][:4], third[1][:4], third[2][:4], *want, tol=TOL)
+    want = oracle.exact_topk(q_hot[:4], corpus, k, mode=oracle.F64, fast=True)
+    assert_topk_matches(fourth[0][:4], fourth[1][:4], fourth[2][:4], *want, tol=TOL)
+
+
 @pytest.mark.parametrize("n,nq,k", [(40_000, 1, 50), (60_000, 64, 100), (45_000, 7, 128), (50_000, 16, 33), (40_000, 130, 64)])
 def test_selection_shared_by_several_blocks_per_query_equals_one_block(gpu, monkeypatch, n, nq, k):
     """k > 32: R = 4 or 8 selection blocks per query share the exact rescoring and the block that arrives last ranks
