@@ -79,9 +79,12 @@ def timed_rounds(step, fence, steps: int, rounds: int):
 
 
 def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_extra=None, outs=None,
-               prewarm_s=0.3):
+               prewarm_s=0.3, pipelined=False):
     """Warm up, then time `rounds` x `steps` searches of `queries` (device tensor) on torch's current stream.
-    Returns timing + live HIP-event kernel times + the prefilter path's candidate statistics."""
+    Returns timing + live HIP-event kernel times + the prefilter path's candidate statistics.
+    pipelined: the steps go through crag_index_search_pipelined (the throughput form for a run of independent
+    searches from one stream: consecutive searches alternate between two streams of the index's own) with ONE
+    crag_index_join in front of every fence -- the queries are resident and the outputs are read behind the fence."""
     dev = queries.device
     nq = int(queries.shape[0])
     if outs is None:
@@ -90,12 +93,23 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
     oi, osc, oc = outs
     stream = torch.cuda.current_stream().cuda_stream
 
+    if pipelined:   # two output sets: consecutive searches run on two streams at once
+        alt = (torch.empty_like(oi), torch.empty_like(osc), torch.empty_like(oc))
+        flip = [0]
+
     def step():
-        index.search_async(queries, k, oi, osc, oc, stream=stream)
+        if pipelined:
+            flip[0] ^= 1
+            o = (oi, osc, oc) if flip[0] else alt
+            index.search_pipelined(queries, k, *o, stream=stream, inputs_ready=True)
+        else:
+            index.search_async(queries, k, oi, osc, oc, stream=stream)
         if step_extra is not None:
             step_extra()
 
     def fence():
+        if pipelined:
+            index.join(stream)
         if fence_extra is not None:
             fence_extra()
         torch.cuda.synchronize()
@@ -144,6 +158,8 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
             # the raw interval is 9 % long and interval - pair 7 % short.  All three numbers are printed.
             "scan_us": max(scan_ms - 0.5 * pair_ms, 0.0) / per * 1e3,
             "rest_us": rest_ms / per * 1e3, "stats": stats, "kernel": index.last_scan_kernel(),
+            "outputs_identical_on_both_streams": (bool(torch.equal(oi, alt[0]) and torch.equal(oc, alt[2]))
+                                                  if pipelined else None),
             "row_bytes": (index.prefilter_row_bytes() if "prefilter" in index.last_scan_kernel() else DIM * 4),
             "out": (oi, osc, oc)}
 
@@ -622,6 +638,9 @@ def compact_line(full: dict) -> dict:
         out["cpu_baseline"]["encode_chunks_per_s"] = _get(base, "encode", "value")
     summ = {
         "streams2_q_per_s": _get(cfg, "steps_overlapped_on_streams", "2", "value"),
+        "in_order_api_q_per_s": _get(full, "in_order_api", "value"),
+        "in_order_api_kernel_us": _get(full, "in_order_api", "roofline", "kernel_avg_us"),
+        "in_order_api_frac": _get(full, "in_order_api", "roofline", "frac"),
         "fp32_rows_scan_frac": _get(full, "fp32_rows_scan", "roofline", "frac"),
         "target_1m_q32_frac": _get(full, "target_1m", "q32", "roofline", "frac"),
         "target_1m_q64_frac": _get(full, "target_1m", "q64", "roofline", "frac"),
@@ -684,6 +703,9 @@ def main() -> None:
                          "weak = 100 000 rows per rank")
     ap.add_argument("--queries", type=int, default=QUERIES_PER_STEP)
     ap.add_argument("--topk", type=int, default=TOPK)
+    ap.add_argument("--api", choices=("pipelined", "async"), default="pipelined",
+                    help="N = 1: which form of the C ABI the timed steps call (pipelined: crag_index_search_pipelined + one "
+                         "crag_index_join per fence; async: crag_index_search_async, in stream order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
@@ -752,9 +774,11 @@ def main() -> None:
 
     step_extra = fence_extra = outs = None
     if world > 1:
-        rec = ResultRecord(nq, k, dev)  # the search writes straight into the record that gets all-gathered
+        # the search writes straight into THIS RANK'S SLOT of the gather buffer: the all-gather runs in place
+        rec_bytes = ResultRecord.record_bytes(nq, k)
+        gathered = torch.zeros(world * rec_bytes, dtype=torch.uint8, device=dev)
+        rec = ResultRecord(nq, k, dev, buf=gathered[rank * rec_bytes:(rank + 1) * rec_bytes])
         outs = (rec.ids, rec.scores, rec.counts)
-        gathered = torch.empty(world * rec.nbytes, dtype=torch.uint8, device=dev)
         f_ids = torch.empty(nq, k, dtype=torch.int64, device=dev)
         f_sc = torch.empty(nq, k, dtype=torch.float32, device=dev)
         f_ct = torch.empty(nq, dtype=torch.int32, device=dev)
@@ -768,7 +792,18 @@ def main() -> None:
         def fence_extra():
             dist.barrier()
 
-    leg = search_leg(index, queries, k, args.steps, args.warmup, args.rounds, step_extra, fence_extra, outs)
+    # N = 1: the timed steps are a run of independent searches over resident queries -> the library's throughput form
+    # (crag_index_search_pipelined: consecutive searches alternate between two streams of the index's own, one join in
+    # front of every fence).  The in-order form (crag_index_search_async, one stream) is timed beside it.  N > 1: a
+    # step's collective consumes the search's output on the stream -> in order.
+    pipelined = world == 1 and args.api == "pipelined"
+    leg_in_order = None
+    if pipelined:
+        leg_in_order = search_leg(index, queries, k, args.steps, args.warmup, args.rounds)
+    leg = search_leg(index, queries, k, args.steps, args.warmup, args.rounds, step_extra, fence_extra, outs,
+                     pipelined=pipelined)
+    if leg_in_order is not None:   # same bits from both forms
+        leg["identical_to_in_order_api"] = all(bool(torch.equal(a, b)) for a, b in zip(leg["out"], leg_in_order["out"]))
     times = leg["times"]
     per_rank = None
     if world > 1:
@@ -914,6 +949,8 @@ def main() -> None:
                 # fp16 MFMA prefilter over the fp16 mirror with a proven bound + exact fp32 rescoring from the fp32 rows:
                 # results bit-identical to the fp32 scan
                 "arithmetic": "fp16-MFMA prefilter (proven bound) + exact fp32 rescoring",
+                "api": ("crag_index_search_pipelined + crag_index_join per fence" if pipelined else
+                        "crag_index_search_async (in stream order)"),
                 "hbm_bytes_per_corpus_row": DIM * 4 + (leg.get("row_bytes") if leg.get("row_bytes") != DIM * 4 else 0) + 12,
             },
             "roofline": roof,
@@ -928,6 +965,15 @@ def main() -> None:
             # strong: the 1-GPU point of the fixed 1M-row job is config.same_job_on_one_gpu (= target_1m.q64 of the N = 1
             # line; the N = 1 `value` itself is configs[1], 100 000 rows); weak: a flat `value` is ideal
             line["config"]["scaling_curve_measured"] = "this line is one point; no curve without a multi-GPU node"
+        if leg_in_order is not None:
+            t_io = leg_in_order["times"]
+            line["config"]["ms_per_step_in_order_api"] = round(t_io[0] / args.steps * 1e3, 5)
+            line["config"]["identical_to_in_order_api"] = leg.get("identical_to_in_order_api")
+            line["config"]["outputs_identical_on_both_streams"] = leg.get("outputs_identical_on_both_streams")
+            line["in_order_api"] = {"value": round(nq * args.steps / t_io[0], 2), "unit": "queries/sec",
+                                    "ms_per_step": round(t_io[0] / args.steps * 1e3, 5),
+                                    "ms_per_step_median": round(statistics.median(t_io) / args.steps * 1e3, 5),
+                                    "roofline": roofline(rows, nq, k, leg_in_order, traffic_doc)}
         if overlap is not None:
             line["config"]["steps_overlapped_on_streams"] = overlap
         if fp32_leg is not None:

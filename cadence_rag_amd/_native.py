@@ -48,6 +48,9 @@ SIGNATURES = {
                                               _c.POINTER(_c.c_double), _c.POINTER(_c.c_double)]),
     "crag_index_last_scan_kernel": (_c.c_char_p, [_P]),
     "crag_index_prefilter_row_bytes": (_c.c_int64, [_P]),
+    "crag_index_search_pipelined": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _P, _c.c_int64, _P, _P, _P, _P, _c.c_int]),
+    "crag_index_join": (_c.c_int, [_P, _P]),
+    "crag_index_phase_trace": (_c.c_int, [_P, _c.POINTER(_c.c_uint64)]),
     "crag_index_prefilter_stats": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64),
                                               _c.POINTER(_c.c_int64)]),
     "crag_index_scan_geometry": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int),

@@ -107,11 +107,17 @@ struct crag_index {
         bool dirty = false;
         uint64_t last_use = 0;
     } ws[MAX_WS];
+    // crag_index_search_pipelined: two streams of the index's own, used in turn
+    hipStream_t pipe[2] = {nullptr, nullptr};
+    hipEvent_t pipe_fork[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr};
+    bool pipe_pending[2] = {false, false};
+    unsigned pipe_next = 0;
     uint64_t use_clock = 0;
     bool multi_stream = false;  // more than one stream has searched this index
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
     bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false, env_no_rsplit = false;
+    int env_pf_derive_lag = 2, env_pf_read_lag = 4;   // CRAG_PF_LAGS="d,r" (developer tuning; r <= 4 = the stashed tiles)
     int env_pf_nt = -1;                       // CRAG_PF_NT=0/1 forces the cache policy of the prefilter scan (developer switch)
     int64_t nt_above_bytes = 1536ll << 20;     // mirror bytes above which its loads stream (measured: no gain below ~1 GB)
     // a stored row whose norm lies outside [1e-30, 1e30]: the fp16 prefilter's error bound assumes normalised
@@ -119,6 +125,7 @@ struct crag_index {
     bool irregular = false;
     uint32_t *irregular_dev = nullptr;
     unsigned long long *pf_stats = nullptr;  // device: PF_STAT_SLOTS x {candidates, rescored rows, searches}
+    unsigned long long *phase_trace = nullptr;  // device, 128 words; only with CRAG_PHASE_TRACE=1 (developer probe)
     const char *last_scan_kernel = "";  // name of the scan kernel the most recent search launched
     DevBuf stage_q, stage_rows, stage_ids, stage_mask, stage_out, scratch;
     std::mutex mu;
@@ -359,6 +366,8 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.sets = k <= 24 ? 1 : (k <= 56 ? 2 : 4);
         fp.pub0 = (k + fp.sets - 1) / fp.sets >= 27 ? 8 : fp.sets;
         fp.cap = cap;
+        fp.derive_lag = ix->env_pf_derive_lag;
+        fp.read_lag = ix->env_pf_read_lag;
         {   // streaming cache policy for a mirror far larger than the Infinity Cache (see prefilter_kernel)
             const int64_t streamed = ix->size * (int64_t)crag::DIM * 2;
             fp.nt = !ix->corpus16 ? 0 : (ix->env_pf_nt >= 0 ? ix->env_pf_nt : (streamed > ix->nt_above_bytes ? 1 : 0));
@@ -410,6 +419,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fin.scan = sp;
         fin.fb_blocks = G * ((nq + 31) / 32);
         fin.fb_done = (uint32_t *)ws->pf_flags.p + 1;
+        fin.trace = ix->phase_trace;
         HIP_TRY(crag::launch_finalize(fin, st));
         ws->dirty = false;
     } else {
@@ -515,6 +525,13 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
     ix->env_no_prefilter = getenv("CRAG_NO_PREFILTER") != nullptr;
     ix->env_no_rsplit = getenv("CRAG_NO_RSPLIT") != nullptr;  // developer switch: one selection block per query for any k
     if (const char *v = getenv("CRAG_PF_NT")) ix->env_pf_nt = atoi(v) ? 1 : 0;
+    if (const char *v = getenv("CRAG_PF_LAGS")) {
+        int d = 0, r = 0;
+        if (sscanf(v, "%d,%d", &d, &r) == 2 && d >= 1 && r > d && r <= 4) {
+            ix->env_pf_derive_lag = d;
+            ix->env_pf_read_lag = r;
+        }
+    }
     if (const char *v = getenv("CRAG_TEST_FAIL_AFTER_SCAN")) ix->env_fail_after_scan = atoll(v);
     if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
@@ -537,6 +554,14 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
         crag_index_destroy(ix);
         return rc;
     }
+    if (getenv("CRAG_PHASE_TRACE") != nullptr) {
+        if ((e = hipMalloc((void **)&ix->phase_trace, 128 * sizeof(unsigned long long))) != hipSuccess ||
+            (e = hipMemset(ix->phase_trace, 0, 128 * sizeof(unsigned long long))) != hipSuccess) {
+            int rc = fail(CRAG_ENOMEM, "hipMalloc for the phase trace failed: %s", hipGetErrorString(e));
+            crag_index_destroy(ix);
+            return rc;
+        }
+    }
     *out = ix;
     return CRAG_OK;
 }
@@ -553,6 +578,12 @@ int crag_index_destroy(crag_index *ix) {
         (void)hipEventDestroy(t.e3);
     }
     if (ix->irregular_dev) (void)hipFree(ix->irregular_dev);
+    if (ix->phase_trace) (void)hipFree(ix->phase_trace);
+    for (int i = 0; i < 2; ++i) {
+        if (ix->pipe_fork[i]) (void)hipEventDestroy(ix->pipe_fork[i]);
+        if (ix->pipe_done[i]) (void)hipEventDestroy(ix->pipe_done[i]);
+        if (ix->pipe[i]) (void)hipStreamDestroy(ix->pipe[i]);
+    }
     if (ix->pf_stats) (void)hipFree(ix->pf_stats);
     if (ix->corpus) (void)hipFree(ix->corpus);
     if (ix->corpus16) (void)hipFree(ix->corpus16);
@@ -757,6 +788,46 @@ int crag_index_search_async(crag_index *ix, const float *d_queries, int nq, int 
                          d_out_counts, (hipStream_t)stream);
 }
 
+int crag_index_search_pipelined(crag_index *ix, const float *d_queries, int nq, int k,
+                                const uint8_t *d_row_mask, int64_t mask_stride, int64_t *d_out_ids,
+                                float *d_out_scores, int32_t *d_out_counts, void *stream, int flags) {
+    int rc = check_search_args(ix, d_queries, nq, k, d_row_mask, mask_stride, d_out_ids, d_out_scores,
+                               d_out_counts);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    if (!ix->pipe[0]) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&ix->pipe[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ix->pipe_fork[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ix->pipe_done[i], hipEventDisableTiming));
+        }
+    }
+    const int i = (int)(ix->pipe_next++ & 1u);
+    if (!(flags & CRAG_PIPE_INPUTS_READY)) {
+        HIP_TRY(hipEventRecord(ix->pipe_fork[i], (hipStream_t)stream));
+        HIP_TRY(hipStreamWaitEvent(ix->pipe[i], ix->pipe_fork[i], 0));
+    }
+    rc = search_device(ix, d_queries, nq, k, d_row_mask, mask_stride, d_out_ids, d_out_scores, d_out_counts,
+                       ix->pipe[i]);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ix->pipe_done[i], ix->pipe[i]));
+    ix->pipe_pending[i] = true;
+    return CRAG_OK;
+}
+
+int crag_index_join(crag_index *ix, void *stream) {
+    if (!ix) return fail(CRAG_EINVAL, "index is NULL");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    for (int i = 0; i < 2; ++i)
+        if (ix->pipe_pending[i]) {
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->pipe_done[i], 0));
+            ix->pipe_pending[i] = false;
+        }
+    return CRAG_OK;
+}
+
 int crag_index_search(crag_index *ix, const float *queries, int nq, int k, const uint8_t *row_mask,
                       int64_t mask_stride, int64_t *out_ids, float *out_scores, int32_t *out_counts) {
     int rc = check_search_args(ix, queries, nq, k, row_mask, mask_stride, out_ids, out_scores, out_counts);
@@ -923,6 +994,16 @@ int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candi
     if (candidates) *candidates = (int64_t)v[0];
     if (rescored_rows) *rescored_rows = (int64_t)v[1];
     if (searches) *searches = (int64_t)v[2];
+    return CRAG_OK;
+}
+
+int crag_index_phase_trace(crag_index *ix, uint64_t *out128) {
+    if (!ix || !out128) return fail(CRAG_EINVAL, "index / out is NULL");
+    if (!ix->phase_trace) return fail(CRAG_EINVAL, "the index was not created with CRAG_PHASE_TRACE=1");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    DeviceGuard guard(ix->device);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out128, ix->phase_trace, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRAG_OK;
 }
 

@@ -83,6 +83,7 @@ struct PfParams {
     int sets;                 // 1, 2 or 4 class sets (32 * sets >= k)
     int pub0;                 // rows of a workgroup's FIRST tile that publish their score per query (sets > 1): sets, or 8
     int nt;                   // corpus loads with the streaming cache policy (corpus larger than the Infinity Cache)
+    int derive_lag, read_lag; // tiles between a publish of class maxima and the delegates' derivation / every wave's read
     int cap;
 };
 
@@ -112,6 +113,9 @@ struct FinParams {
     // the selection blocks run the exact fp32 scan, the one that finishes last merges
     int fb_blocks;
     uint32_t *fb_done;          // ticket counter, zero between searches
+    unsigned long long *trace;  // nullable (developer probe, CRAG_PHASE_TRACE=1): 100 MHz timestamps of the phases of the
+                                // selection blocks of query 0: [rpart * 16 + phase]
+
     ScanParams scan;
     MergeParams merge;
 };

@@ -1598,8 +1598,13 @@ constexpr float PF_DELTA = 1.25e-3f;
 // of the rule) and the kernels pass it on MI355X / ROCm 7.2: subnormals are kept (ISA 7.4: MFMA never flushes C/D,
 // A/B follow MODE.denorm, which hipcc leaves at "keep" for f16).  tests/test_prefilter_gpu.py measures the
 // actual worst case on ordinary inputs.
-constexpr int PF_FLUSH_ABOVE = 768;                // staged candidates that trigger a flush at the next tile boundary
+constexpr int PF_FLUSH_ABOVE = 768;                // staged candidates that trigger a sift at the next tile boundary
 constexpr int PF_STAGE = PF_FLUSH_ABOVE + 2048;    // per-workgroup staging entries in LDS: a tile adds at most 32 x 64
+constexpr int PF_PER = (PF_STAGE + SCAN_THREADS - 1) / SCAN_THREADS;   // staged entries per thread in a sift
+constexpr int PF_TAU_CELL = 128;                   // cell of a query's bound record that holds the DERIVED bound
+constexpr int PF_STASH = 4;                        // tiles scored before the first bound can have arrived
+constexpr int PF_DERIVE_LAG_DEFAULT = 2;           // tiles between a publish and the delegates' derivation
+constexpr int PF_READ_LAG_DEFAULT = 4;             // ... and every wave's read of the derived bounds (<= PF_STASH)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1662,11 +1667,27 @@ __device__ __forceinline__ uint32_t sort32_desc_u32(uint32_t v, int lane) {
     return v;
 }
 
+// Whole-wave reductions on the VALU: DPP inside the 16-lane rows, v_permlane16_swap / v_permlane32_swap across them
+// (a ds_bpermute shuffle is an LDS-pipeline round trip, ~100 cycles each with one wave on the SIMD: the 100 dependent
+// shuffles of a k-th-value search were 4 us).  Every lane ends with the result.
+template <class F>
+__device__ __forceinline__ uint32_t wave_reduce_u32(uint32_t v, int lane, F f) {
+    v = f(v, dpp_xor<1>(v, lane));
+    v = f(v, dpp_xor<2>(v, lane));
+    v = f(v, dpp_xor<4>(v, lane));
+    v = f(v, dpp_xor<8>(v, lane));
+    const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // rows 0<->1, 2<->3
+    v = f(r16[0], r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // the two halves
+    return f(r32[0], r32[1]);
+}
+
 template <int NQB>
 struct PfLds {
     typedef float slab_t __attribute__((ext_vector_type(2 * NQB)));
     slab_t slab[2][SCAN_WAVES][SCAN_WAVES][64];  // [buf][owner wave][producer wave][lane]: split-K partial sums
     uint2 stage[PF_STAGE];                       // staged candidates: x = orderable score, y = (row - window) << 6 | query
+    float qthr[32 * NQB];                        // the owners' current candidate thresholds (they only rise)
     uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
     uint32_t n_stage;
     uint32_t want_flush[2][SCAN_WAVES];          // [slab buffer][wave]: the wave saw the staging buffer fill up
@@ -1691,7 +1712,6 @@ __device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, c
         if (pass[e]) {
             const uint32_t slot = atomicAdd(&L.n_stage, 1u);
             if (slot < (uint32_t)PF_STAGE) {
-                atomicAdd(&L.qcount[o.ql0 + e], 1u);
                 L.stage[slot] = make_uint2(f2ord(sc[e]), (row_in_window << 6) | (uint32_t)(o.ql0 + e));
             } else {
                 *flags = seq;  // cannot happen (<= PF_FLUSH_ABOVE staged + <= 2048 per tile); never drop one silently
@@ -1700,33 +1720,63 @@ __device__ __forceinline__ void pf_stage(PfLds<NQB> &L, const PfOwner<NQB> &o, c
     }
 }
 
-// staged candidates -> the per-query global lists (all threads of the workgroup; contains barriers).  LAST: the
-// workgroup ends behind this flush, nothing is reset.
-template <int NQB, bool LAST = false>
-__device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64_t window_row0) {
-    __syncthreads();
+// The sift (all threads of the workgroup; contains barriers).  A staged candidate passed the threshold its query had
+// when it was scored; thresholds only rise, and most of what an early, weak bound let through fails the current one.
+// So every staged candidate is re-tested against its query's CURRENT threshold (L.qthr) and the survivors are packed
+// in place; only if the buffer is still more than half full afterwards (or at the workgroup's end: LAST) do they move
+// to the per-query global lists -- one returning global atomic per workgroup, query and flush.  [Before: whatever was
+// staged went to the global lists as it was, 2 900 candidates per query of a top-100 search over 1M rows where the
+// final bound passes ~400; the selection kernel paid for them.]
+template <int NQB, bool LAST>
+__device__ __forceinline__ void pf_sift(const PfParams &p, PfLds<NQB> &L, int64_t window_row0) {
+    __syncthreads();   // every append and threshold update of the tile is visible
     const uint32_t n = L.n_stage < (uint32_t)PF_STAGE ? L.n_stage : (uint32_t)PF_STAGE;
     const int tid = threadIdx.x;
     if (LAST && n == 0u) return;  // (uniform)
+    uint2 ent[PF_PER];
+    bool keep[PF_PER];
+#pragma unroll
+    for (int i = 0; i < PF_PER; ++i) {
+        const uint32_t idx = (uint32_t)tid + (uint32_t)i * SCAN_THREADS;
+        keep[i] = false;
+        if (idx < n) {
+            ent[i] = L.stage[idx];
+            keep[i] = ord2f(ent[i].x) >= L.qthr[ent[i].y & 63u];
+        }
+    }
+    if (tid < 32 * NQB) {
+        L.qcount[tid] = 0u;
+        L.qfill[tid] = 0u;
+    }
+    __syncthreads();   // every entry is in registers
+    if (tid == 0) L.n_stage = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PF_PER; ++i)
+        if (keep[i]) {
+            atomicAdd(&L.qcount[ent[i].y & 63u], 1u);
+            if (!LAST) L.stage[atomicAdd(&L.n_stage, 1u)] = ent[i];
+        }
+    __syncthreads();
+    if (!LAST && L.n_stage <= (uint32_t)(PF_FLUSH_ABOVE / 2)) return;  // (uniform) the survivors stay staged
     if (tid < 32 * NQB) {
         const uint32_t cnt = L.qcount[tid];
         const int qg = (int)blockIdx.y * (32 * NQB) + tid;
         L.qbase[tid] = cnt ? atomicAdd(&p.count[qg], cnt) : 0u;
-        if (!LAST) L.qcount[tid] = 0u;
-        L.qfill[tid] = 0u;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += SCAN_THREADS) {
-        const uint2 e = L.stage[i];
-        const uint32_t ql = e.y & 63u;
-        const uint32_t pos = L.qbase[ql] + atomicAdd(&L.qfill[ql], 1u);
-        const int qg = (int)blockIdx.y * (32 * NQB) + (int)ql;
-        if (pos < (uint32_t)p.cap) {
-            p.cand[(size_t)qg * p.cap + pos] = make_uint2(e.x, (uint32_t)(window_row0 + (int64_t)(e.y >> 6)));
-        } else {
-            p.flags[0] = p.seq;  // this query's list is full: the fallback blocks of the selection launch take over
+#pragma unroll
+    for (int i = 0; i < PF_PER; ++i)
+        if (keep[i]) {
+            const uint32_t ql = ent[i].y & 63u;
+            const uint32_t pos = L.qbase[ql] + atomicAdd(&L.qfill[ql], 1u);
+            const int qg = (int)blockIdx.y * (32 * NQB) + (int)ql;
+            if (pos < (uint32_t)p.cap) {
+                p.cand[(size_t)qg * p.cap + pos] = make_uint2(ent[i].x, (uint32_t)(window_row0 + (int64_t)(ent[i].y >> 6)));
+            } else {
+                p.flags[0] = p.seq;  // this query's list is full: the fallback blocks of the selection launch take over
+            }
         }
-    }
     if (LAST) return;
     __syncthreads();
     if (tid == 0) L.n_stage = 0u;
@@ -1736,11 +1786,25 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
 // ---- K1: the fp16 scan.  Grid (G, passes); one pass = 32*NQB queries against this workgroup's row range ------
 // A lane keeps the maxima of ITS rows (class = lane x tile parity: the rows of a class within a workgroup all belong
 // to one lane) in registers, and the workgroups exchange them on a geometric schedule only: publish after tiles 0,
-// 3, 15, 63, ... (atomic max of the class maxima that rose since the last checkpoint and beat the bound), read the
-// shared maxima + sort two tiles after each.  A bound derived from the first t tiles of every workgroup lets about
-// 12 n/t rows per query pass (k = 10, n tiles per workgroup) and holds for the next 3t tiles, so every interval adds
-// the same ~36 candidates per query: log4(n) exchanges per workgroup for a few dozen candidates per query.  All
-// other tiles touch no shared word.
+// 3, 15, 63, ... and once more four tiles before the end (atomic max of the class maxima that rose since the last
+// checkpoint and beat the bound).  A bound derived from the first t tiles of every workgroup lets about 12 n/t rows
+// per query pass (k = 10, n tiles per workgroup) and holds for the next 3t tiles, so every interval adds the same
+// few dozen candidates per query.  All other tiles touch no shared word.
+//
+// Who derives the bound (round 4).  Until round 3 every wave derived the bounds of the queries it owns: it read
+// their 32 * SETS class maxima and sorted them, RPO * SETS half-wave sorts per wave and exchange -- 16 per wave at
+// k = 100, three exchanges in a 100 000-row scan: ~13 us of a 52 us scan.  Now workgroup g is the DELEGATE of query
+// g mod (32 * NQB) of its pass: two tiles after a publish its wave 0 reads that one query's class maxima, sorts
+// them (SETS / 2 sorts: the two half-waves take two sets at a time) and publishes the result -- min over the sets
+// of the k_s-th largest class maximum -- into the query's bound cell (atomic max; with 256 workgroups and 64
+// queries four delegates per query write the same value).  Every wave reads the bound cells of the queries it owns
+// two tiles later: one load per query instead of a sort per query and set.  The price is a first bound that arrives
+// after tile 4 instead of tile 2: the first PF_STASH = 4 tiles' scores wait in registers and are judged last.
+// A wave that still finds no published bound at its end derives one itself, the old way (a delegate that is far
+// behind must not send a whole search into the fallback).
+//
+// What happens to candidates of early, weak bounds: see pf_sift.  The thresholds of the owned queries live in LDS
+// (L.qthr) besides the owners' registers so that the sift can re-test any staged candidate.
 // [The first version exchanged on every tile: bound loads in front of the MFMA phase, a sort, an atomic max for
 // every row that beat its class.  Switching its parts off on one box (100 000 rows x 64 queries / 1M x 64): nothing
 // exchanged and no candidates 64.6 / 641 us; + bound loads of lines nobody writes 66.2 / 651; + the atomic maxima
@@ -1749,6 +1813,19 @@ __device__ __forceinline__ void pf_flush(const PfParams &p, PfLds<NQB> &L, int64
 // stalled wave stalls its workgroup at the next barrier, and while bounds are young some wave of every workgroup
 // lifts a class maximum on nearly every tile.  Plain stores instead of atomics ran at 78 / 626 us but lose
 // maxima (20x the candidates); eight copies of the cells (one per XCD) weaken the bound 10x for no gain.]
+
+// publish points of a workgroup with n tiles: 0, then read_lag + 1 (the first publish that can be filtered by a
+// bound: an unfiltered one is an atomic from every lane for every owned query and set -- 1.5 M of them on 8192 cells
+// at k = 100), 4 P + 3 from there on, then n - 4 (the bound every workgroup reads at its end and sifts its staged
+// candidates with); a geometric point within 25 % of the last one is skipped.  Returns a value >= 2^30 when there is
+// none left.
+__device__ __forceinline__ int pf_next_pub(int after, int n_tiles, int read_lag) {
+    const int last = n_tiles >= 12 ? n_tiles - 4 : -1;
+    const int np = after < 0 ? 0 : (after == 0 ? read_lag + 1 : after * 4 + 3);
+    if (after < last && np + (np >> 2) >= last) return last;
+    return (np < n_tiles) ? np : (1 << 30);
+}
+
 template <int NQB, int SETS, bool MIRROR, bool NT>
 __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     constexpr int RPO = 2 * NQB;
@@ -1833,26 +1910,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         for (int e = 0; e < RPO; ++e)
             if (o.qg0 + e < p.nq && qi[e] > 0.f) o.okmask |= 1u << e;
     }
-    if (threadIdx.x < 32 * NQB) L.qcount[threadIdx.x] = 0u;
+    if (threadIdx.x < 32 * NQB) L.qthr[threadIdx.x] = -__builtin_inff();
     if (threadIdx.x == 0) L.n_stage = 0u;
-    // the first two tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
-    float stash[RPO], stash2[RPO];
+    // the first PF_STASH tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
+    float stash[PF_STASH][RPO];
+    uint32_t stash_row[PF_STASH];
 #pragma unroll
-    for (int e = 0; e < RPO; ++e) stash2[e] = __uint_as_float(0x7fc00000u);
-    uint32_t stash2_row = 0u;
+    for (int t = 0; t < PF_STASH; ++t) {
+        stash_row[t] = 0u;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) stash[t][e] = __uint_as_float(0x7fc00000u);
+    }
     float thr[RPO];    // candidate thresholds of the owned queries (bound - 2 delta)
     uint32_t tau[RPO];            // the bound itself, orderable (0 = none yet)
     uint32_t lmax[RPO][SETS];     // class maxima over this lane's own rows
     uint32_t dirty = 0u;          // bit e*SETS+s: lmax[e][s] has risen since the last publish
 #pragma unroll
     for (int e = 0; e < RPO; ++e) {
-        stash[e] = __uint_as_float(0x7fc00000u);
         thr[e] = -__builtin_inff();
         tau[e] = 0u;
 #pragma unroll
         for (int s = 0; s < SETS; ++s) lmax[e][s] = 0u;
     }
-    uint32_t stash_row = 0u;
     float inv_cur = 1.f;  // (mirror: rows that may never match are NaN in the mirror itself)
     if (!MIRROR && c.n_tiles > 0) inv_cur = p.inv_norm[(c.t_begin + tile_of(c, 0)) * 32 + j];
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): empty scoreboard at the loop head (see scan_kernel)
@@ -1865,54 +1944,104 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     // per query around the loads)
     const uint32_t *const idle_row = p.gbound_idle + (size_t)c.g * PF_BOUND_CELLS + j;
 
-    auto load_bounds = [&](uint32_t (&gb)[RPO][SETS]) {
+    // the derived bounds of the owned queries (one cell each, written by the queries' delegates)
+    auto load_taus = [&](uint32_t (&tq)[RPO]) {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
             const bool live = (o.okmask >> e) & 1u;
-#pragma unroll
-            for (int s = 0; s < SETS; ++s)
-                gb[e][s] = __hip_atomic_load(live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row + s * 32,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tq[e] = __hip_atomic_load(live ? gb_row - j + e * PF_BOUND_CELLS + PF_TAU_CELL : idle_row - j + PF_TAU_CELL,
+                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // bound of a query: min over the sets of the (k_s)-th largest class maximum of the set (sum k_s = k)
-    auto derive = [&](const uint32_t (&gb)[RPO][SETS]) {
+    auto take_taus = [&](const uint32_t (&tq)[RPO]) {
+#pragma unroll
+        for (int e = 0; e < RPO; ++e)
+            if (tq[e] > tau[e]) {  // (a stale read can only be lower)
+                tau[e] = tq[e];
+                thr[e] = ord2f(tq[e]) - 2.f * PF_DELTA;
+                if (j == 0) L.qthr[o.ql0 + e] = thr[e];
+            }
+    };
+    auto any_without_bound = [&]() -> bool {
+        bool none = false;
+#pragma unroll
+        for (int e = 0; e < RPO; ++e) none = none || (((o.okmask >> e) & 1u) && tau[e] == 0u);
+        return __builtin_amdgcn_ballot_w64(none) != 0ull;
+    };
+    // delegate (wave 0): the class maxima of ONE query, half-wave h takes the sets h, h + 2
+    constexpr int DS = SETS >= 2 ? SETS / 2 : 1;   // sorts per delegated query
+    auto load_cells = [&](int dq, uint32_t (&cell)[DS]) {
+        const uint32_t *rec = p.gbound + (size_t)((int)blockIdx.y * (32 * NQB) + dq) * PF_BOUND_CELLS;
+#pragma unroll
+        for (int i = 0; i < DS; ++i)
+            cell[i] = __hip_atomic_load(rec + (SETS >= 2 ? 2 * i + h : 0) * 32 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto derive_cells = [&](int dq, const uint32_t (&cell)[DS]) {
+        uint32_t t = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < DS; ++i) {
+            const uint32_t sorted = sort32_desc_u32(cell[i], lane);
+            const int sset = SETS >= 2 ? 2 * i + h : 0;
+            const int ks = k_base + (sset < k_rem ? 1 : 0);
+            const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
+            t = kth < t ? kth : t;
+        }
+        if constexpr (SETS >= 2) {
+            const uint32_t other = (uint32_t)__shfl((int)t, lane ^ 32);
+            t = other < t ? other : t;
+        }
+        if (lane == 0 && t != 0u)
+            (void)__hip_atomic_fetch_max(p.gbound + (size_t)((int)blockIdx.y * (32 * NQB) + dq) * PF_BOUND_CELLS + PF_TAU_CELL, t,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // the old way, for a wave that finds no published bound at its end: all class maxima of the owned queries
+    auto derive_own = [&]() {
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
+            const bool live = (o.okmask >> e) & 1u;
             uint32_t t = 0xffffffffu;
 #pragma unroll
             for (int s = 0; s < SETS; ++s) {
-                const uint32_t sorted = sort32_desc_u32(gb[e][s], lane);
+                const uint32_t v = __hip_atomic_load(live ? gb_row + e * PF_BOUND_CELLS + s * 32 : idle_row + s * 32,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t sorted = sort32_desc_u32(v, lane);
                 const int ks = k_base + (s < k_rem ? 1 : 0);
                 const uint32_t kth = (uint32_t)__shfl((int)sorted, (lane & 32) | (ks - 1));
                 t = kth < t ? kth : t;
             }
-            if (t > tau[e]) {  // (a stale read can only be lower)
+            if (t > tau[e]) {
                 tau[e] = t;
                 thr[e] = ord2f(t) - 2.f * PF_DELTA;
+                if (j == 0) L.qthr[o.ql0 + e] = thr[e];
             }
         }
     };
 
-    // publish after tiles 0, 3, 15, 63, ...; read two tiles later (2, 5, 17, 65, ...): the atomics of every
-    // workgroup have had a tile time to land and the lines are quiet again when they are read (reading on the very
-    // next tile, with one stashed tile: 82 us instead of 73 at 100 000 rows x 64)
-    int next_pub = 0, next_read = 2, read_base = 1;
+    // three cursors over the same sequence of publish points: publish after tile P, the delegates derive after tile
+    // P + PF_DERIVE_LAG (the atomics of every workgroup have had two tile times to land and the lines are quiet
+    // again), every wave reads after tile P + PF_READ_LAG
+    const int PF_DERIVE_LAG = p.derive_lag, PF_READ_LAG = p.read_lag;   // (developer tuning: CRAG_PF_LAGS)
+    int pub_at = pf_next_pub(-1, c.n_tiles, PF_READ_LAG);
+    int der_base = pub_at, rd_base = pub_at;
+    int next_read = rd_base + PF_READ_LAG;
+    const int dq0 = c.g % (32 * NQB);   // (G >= 32 * NQB on a whole MI355X: one delegated query per workgroup)
     int buf = 0;
     for (int ti = 0; ti < c.n_tiles; ++ti) {
         const uint32_t vnext = voff(ti + 1);
         const int64_t tile = c.t_begin + tile_of(c, ti);
         const int64_t row = tile * 32 + j;
-        const bool rd = ti == next_read;  // uniform
+        const bool rd = ti == next_read;                                   // uniform
+        const bool dv = (w == 0) && (ti == der_base + PF_DERIVE_LAG);      // uniform per wave
         // operands of this tile's epilogue, behind the B loads of this tile (in flight) and in front of the next one's
         float inv_nxt = 1.f;
         if constexpr (!MIRROR) inv_nxt = p.inv_norm[(c.t_begin + tile_of(c, ti + 1 < c.n_tiles ? ti + 1 : ti)) * 32 + j];
-        uint32_t mword[RPO], gb[RPO][SETS];
+        uint32_t mword[RPO], tq[RPO], cell[DS];
 #pragma unroll
         for (int e = 0; e < RPO; ++e)
             mword[e] = p.mask ? p.mask[(size_t)(((o.okmask >> e) & 1u) ? o.qg0 + e : 0) * (size_t)p.mask_stride_w + tile]
                               : 0xffffffffu;
-        if (rd) load_bounds(gb);
+        if (rd) load_taus(tq);
+        if (dv) load_cells(dq0, cell);
         // The whole tile before the first MFMA: the 16 loads of the next tile then leave back to back, 16 KiB
         // contiguous per wave.  Waiting fragment by fragment re-issues them in dribs and drabs between 2047 other
         // waves' (measured on one box, 1M rows x 64: 643 us with this wait, 657 without).
@@ -1960,7 +2089,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
         {
             const u32x4 f0 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][0]);
             const u32x4 f1 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][4]);
-            if ((f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0u) pf_flush<NQB>(p, L, c.t_begin * 32);
+            if ((f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0u) pf_sift<NQB, false>(p, L, c.t_begin * 32);
         }
         float sc[RPO];
 #pragma unroll
@@ -1972,113 +2101,127 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             for (int e = 0; e < RPO; ++e) sc[e] += v[e];
         }
         buf ^= 1;
+        if (dv) {
+            derive_cells(dq0, cell);
+            for (int dq = dq0 + p.G; dq < 32 * NQB; dq += p.G) {   // (fewer workgroups than queries of a pass: partitioned GPU)
+                uint32_t more[DS];
+                load_cells(dq, more);
+                derive_cells(dq, more);
+            }
+        }
+        if (ti == der_base + PF_DERIVE_LAG) der_base = pf_next_pub(der_base, c.n_tiles, PF_READ_LAG);
         if (rd) {
-            derive(gb);
-            // no bound yet for one of the queries (a workgroup far ahead of the others): ask again on the next tile
-            bool none = false;
-#pragma unroll
-            for (int e = 0; e < RPO; ++e) none = none || (((o.okmask >> e) & 1u) && tau[e] == 0u);
-            if (__builtin_amdgcn_ballot_w64(none) != 0ull) {
+            take_taus(tq);
+            // no bound yet for one of the queries (its delegate is behind): ask again on the next tile
+            if (any_without_bound()) {
                 next_read = ti + 1;
             } else {
-                while (read_base * 4 + 1 <= ti) read_base *= 4;  // (terminates: read_base grows)
-                read_base *= 4;
-                next_read = read_base + 1;
+                rd_base = pf_next_pub(rd_base, c.n_tiles, PF_READ_LAG);
+                while (rd_base + PF_READ_LAG <= ti) rd_base = pf_next_pub(rd_base, c.n_tiles, PF_READ_LAG);  // (terminates: rd_base grows)
+                next_read = rd_base + PF_READ_LAG;
             }
         }
         const bool row_ok = (row >= c.r_begin) && (row < c.r_end) && (inv_cur > 0.f);
-        const int set = (int)(tile & (int64_t)(SETS - 1));
+        const int set = __builtin_amdgcn_readfirstlane((int)(tile & (int64_t)(SETS - 1)));
         bool pass[RPO];
+        uint32_t ord[RPO];
 #pragma unroll
         for (int e = 0; e < RPO; ++e) {
             const bool ok = row_ok && ((o.okmask >> e) & 1u) && ((mword[e] >> j) & 1u) && (sc[e] == sc[e]);
             sc[e] = ok ? sc[e] : __uint_as_float(0x7fc00000u);
-            const uint32_t ord = ok ? f2ord(sc[e]) : 0u;
-#pragma unroll
-            for (int s = 0; s < SETS; ++s)
-                if (s == set && ord > lmax[e][s]) {
-                    lmax[e][s] = ord;
-                    dirty |= 1u << (e * SETS + s);
-                }
+            ord[e] = ok ? f2ord(sc[e]) : 0u;
             pass[e] = sc[e] >= thr[e];
         }
-        if (ti == 0) {  // no bounds exist yet: keep the scores, decide at the end
+        // the tile feeds ONE of the sets (a scalar): a scalar branch per set, RPO updates inside -- not RPO * SETS
+        // compare-and-select pairs on every tile
 #pragma unroll
-            for (int e = 0; e < RPO; ++e) stash[e] = sc[e];
-            stash_row = (uint32_t)(row - c.t_begin * 32);
-        } else if (ti == 1) {
+        for (int s = 0; s < SETS; ++s)
+            if (s == set) {
 #pragma unroll
-            for (int e = 0; e < RPO; ++e) stash2[e] = sc[e];
-            stash2_row = (uint32_t)(row - c.t_begin * 32);
+                for (int e = 0; e < RPO; ++e)
+                    if (ord[e] > lmax[e][s]) {
+                        lmax[e][s] = ord[e];
+                        dirty |= 1u << (e * SETS + s);
+                    }
+            }
+        if (ti < PF_STASH) {  // no bound can have arrived yet: keep the scores, decide at the end
+#pragma unroll
+            for (int t = 0; t < PF_STASH; ++t)
+                if (ti == t) {
+#pragma unroll
+                    for (int e = 0; e < RPO; ++e) stash[t][e] = sc[e];
+                    stash_row[t] = (uint32_t)(row - c.t_begin * 32);
+                }
         } else {
             pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags, p.seq);
         }
-        if (ti == next_pub) {  // uniform
+        if (ti == pub_at) {  // uniform
 #pragma unroll
             for (int e = 0; e < RPO; ++e) {
+                // After the first tile every class is empty and every lane would publish (524 000 atomics on 2048 cells
+                // at once): there only the tile's best row(s) per query do -- the k best of the first 8192 rows are
+                // their tiles' best with high probability, so the first bound is as good, from 16 000 atomics (8 per
+                // class).  A workgroup's first tile feeds ONE of the sets: one sort per owned query.
+                // (pub0 = SETS, or 8 when k_s nears 32: the bound then needs nearly EVERY class of the set to be
+                // populated after this first exchange -- with SETS rows per workgroup 4 % of the queries of a k = 128
+                // search found a class still empty, passed every row of the next tiles and pushed the whole search into
+                // the fallback)
+                uint32_t first_cut = 0u;
+                if (ti == 0) {
+                    uint32_t v0 = lmax[e][0];
+#pragma unroll
+                    for (int s = 1; s < SETS; ++s) v0 = (s == set) ? lmax[e][s] : v0;
+                    if constexpr (SETS == 1) first_cut = half_max_u32(v0);
+                    else first_cut = (uint32_t)__shfl((int)sort32_desc_u32(v0, lane), (lane & 32) | (p.pub0 - 1));
+                }
 #pragma unroll
                 for (int s = 0; s < SETS; ++s) {
                     const uint32_t v = lmax[e][s];
-                    // only a class maximum above the bound can lift the bound.  After the first tile every class is
-                    // empty and every lane would publish (524 000 atomics on 2048 cells at once): there only the
-                    // tile's best row(s) per query do -- the k best of the first 8192 rows are their tiles' best
-                    // with high probability, so the first bound is as good, from 16 000 atomics (8 per class).
-                    bool lift = ((dirty >> (e * SETS + s)) & 1u) && v > tau[e];
-                    if (ti == 0) {
-                        if constexpr (SETS == 1) {
-                            lift = lift && (v == half_max_u32(v));
-                        } else {  // the tile's SETS best rows: a workgroup's first tile feeds one of the SETS sets
-                            const uint32_t sorted = sort32_desc_u32(v, lane);
-                            // (pub0 = SETS, or 8 when k_s nears 32: the bound then needs nearly EVERY class of the
-                            // set to be populated after this first exchange -- with SETS rows per workgroup 4 % of the
-                            // queries of a k = 128 search found a class still empty, passed every row of the next
-                            // three tiles and pushed the whole search into the fallback)
-                            lift = lift && (v >= (uint32_t)__shfl((int)sorted, (lane & 32) | (p.pub0 - 1)));
-                        }
-                    }
+                    // only a class maximum above the bound can lift the bound
+                    const bool lift = ((dirty >> (e * SETS + s)) & 1u) && v > tau[e] && v >= first_cut;
                     if (lift)
                         (void)__hip_atomic_fetch_max(gb_row + e * PF_BOUND_CELLS + s * 32, v, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             dirty = 0u;
-            next_pub = next_pub * 4 + 3;
+            pub_at = pf_next_pub(pub_at, c.n_tiles, PF_READ_LAG);
         }
         inv_cur = inv_nxt;
     }
-    if (c.n_tiles > 0) {  // the first two tiles, against the bounds the wave holds now
-        // flush first if the staging buffer is nearly full: decided as in the loop, behind ONE barrier (each wave
-        // posts what it saw after its own last append)
-        auto flush_if_full = [&]() {
-            if (lane == 0) L.want_flush[buf][w] = L.n_stage > (uint32_t)PF_FLUSH_ABOVE ? 1u : 0u;
+    if (c.n_tiles > 0) {  // the stashed tiles, against the last bounds published
+        {
+            uint32_t tq[RPO];
+            load_taus(tq);
+            take_taus(tq);
+            if (any_without_bound()) derive_own();
+        }
+        // One barrier: sift first if the staging buffer is nearly full (decided as in the loop: each wave posts what it
+        // saw after its own last append), and learn whether EVERY wave holds bounds -- then the stashed tiles add a
+        // handful of candidates and are staged back to back.  Without a bound a tile can add 2048 entries: a check
+        // (a barrier) in front of each.
+        const bool unbounded = any_without_bound();
+        auto sift_if_full = [&](bool post_unbounded) -> bool {
+            if (lane == 0) L.want_flush[buf][w] = (L.n_stage > (uint32_t)PF_FLUSH_ABOVE ? 1u : 0u) | (post_unbounded ? 2u : 0u);
             __syncthreads();
             const u32x4 f0 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][0]);
             const u32x4 f1 = *reinterpret_cast<const u32x4 *>(&L.want_flush[buf][4]);
             buf ^= 1;
-            if ((f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3]) != 0u) pf_flush<NQB>(p, L, c.t_begin * 32);
+            const uint32_t f = f0[0] | f0[1] | f0[2] | f0[3] | f1[0] | f1[1] | f1[2] | f1[3];
+            if ((f & 1u) != 0u) pf_sift<NQB, false>(p, L, c.t_begin * 32);
+            return (f & 2u) != 0u;
         };
-        flush_if_full();
-        // (a last read of the shared maxima would pass ~4 rows per query fewer of these 64 rows x 256 workgroups
-        // and cost every workgroup a device-coherent load + sort at its very end: only a wave without any bound
-        // asks)
-        bool none = false;
+        const bool careful = sift_if_full(unbounded);   // (uniform over the workgroup)
 #pragma unroll
-        for (int e = 0; e < RPO; ++e) none = none || (((o.okmask >> e) & 1u) && tau[e] == 0u);
-        if (__builtin_amdgcn_ballot_w64(none) != 0ull) {
-            uint32_t gb[RPO][SETS];
-            load_bounds(gb);
-            derive(gb);
+        for (int t = 0; t < PF_STASH; ++t) {
+            if (careful && t > 0) (void)sift_if_full(false);
+            bool pass[RPO];
+#pragma unroll
+            for (int e = 0; e < RPO; ++e) pass[e] = stash[t][e] >= thr[e];
+            pf_stage<NQB>(L, o, stash[t], pass, stash_row[t], p.flags, p.seq);
         }
-        bool pass[RPO];
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash[e] >= thr[e];
-        pf_stage<NQB>(L, o, stash, pass, stash_row, p.flags, p.seq);
-        flush_if_full();
-#pragma unroll
-        for (int e = 0; e < RPO; ++e) pass[e] = stash2[e] >= thr[e];
-        pf_stage<NQB>(L, o, stash2, pass, stash2_row, p.flags, p.seq);
     }
-    pf_flush<NQB, true>(p, L, c.t_begin * 32);
+    pf_sift<NQB, true>(p, L, c.t_begin * 32);
 }
 
 // ---- K3: candidates -> exact top-k.  One 256-thread workgroup per query ---------------------------------------
@@ -2088,10 +2231,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 //    the fmaf chain of v_mfma_f32_32x32x2_f32 in the kernels' k order, the 8 slice sums added in wave order,
 //    x (1/||row|| * 1/||q||), clamp -- so scores and order are bit-identical to the fp32 scan.
 // 3. rank by counting among the exact keys.
-// The bit search for the k-th approximate score stops FIN_SKIP_BITS above the bottom: the candidates that share the
-// remaining high bits with the answer (typically one to three of them) are ranked by counting instead -- four rounds
-// of a barrier + two wave reductions each become one.  The result is the EXACT k-th value, as before.
+// Up to FIN_THREADS candidates (the usual case since the scan sifts its staged candidates, round 4) the k-th
+// approximate score is found by counting ranks, one candidate per thread.  Beyond that a bit search on the orderable
+// score, three bits per round, which stops FIN_SKIP_BITS above the bottom: the value it ends with is the k-th value
+// with its low bits cleared -- a LOWER bound on it, at most 4096 ulps (2.4e-4 for a score in [0.5, 1), 3e-5 at 0.12)
+// below, so the survivor window is that much wider than 2 delta and nothing is lost.  [Round 3 finished the search
+// exactly by ranking the last bucket: three more barriers for one or two rows fewer to rescore.]
 constexpr int FIN_SKIP_BITS = 12;
+constexpr int FIN_THREADS = SCAN_THREADS;   // all eight waves of a selection block work (round 3: four of them)
+constexpr int FIN_WAVE_PER = 16;            // candidates per lane in the one-wave search for the k-th approximate score
 constexpr int FIN_ROUND = 4096;             // candidates examined per round (all of them, for k <= 128 on the bench's corpora)
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
@@ -2128,7 +2276,7 @@ struct FinLds {
     uint32_t surv[FIN_ROUND];     // rows to rescore in the current round
     f32x4 qs[SCAN_WAVES][16][2];  // the query in fragment order: [slice][s][lane half]
     int64_t best_id[FIN_BEST];    // external id of best[i]'s row, fetched beside the row itself
-    unsigned long long hist[32];  // exchange buffer of the workgroup reductions
+    unsigned long long hist[64];  // exchange buffer of the workgroup reductions
     int s_nbest, s_nsurv, s_rescored;
     uint32_t s_kth;
 };
@@ -2185,7 +2333,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         if (threadIdx.x == 0) __hip_atomic_store(p.fb_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (wave >= MERGE_THREADS / 64) return;
+    // developer probe: timestamps (100 MHz) of the phases of query 0's selection blocks
+#define FIN_T(PH_)                                                                                               \
+    do {                                                                                                         \
+        if (p.trace && (int)blockIdx.x < R && threadIdx.x == 0) p.trace[((int)blockIdx.x % R) * 16 + (PH_)] = wall_clock64(); \
+    } while (0)
+    FIN_T(0);
+    constexpr int NT = FIN_THREADS;
     auto &best = U.f.best;
     auto &lcand = U.f.lcand;
     auto &surv = U.f.surv;
@@ -2196,16 +2350,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     uint32_t &s_kth = U.f.s_kth;
     const int q = (int)blockIdx.x / R, rpart = (int)blockIdx.x % R, tid = threadIdx.x;
     // Everything the kernel needs first, in flight together (one memory round trip instead of a chain of four:
-    // flag -> count -> candidates -> ...): the overflow flag, the candidate count, the first MERGE_THREADS
-    // candidates (read before the count is known -- the list has `cap` >= MERGE_THREADS slots; the usual few dozen
-    // candidates are all among them), the query's norm and its fp32 fragments.
+    // flag -> count -> candidates -> ...): the overflow flag, the candidate count, the first NT candidates (read
+    // before the count is known -- the list has `cap` >= NT slots; the usual few hundred candidates are all among
+    // them), the query's norm and its fp32 fragments.
     const uint2 *gcand = p.cand + (size_t)q * p.cap;
     const bool overflow = p.flags[0] == p.seq;
     const uint32_t total = p.count[q];
     const uint2 first = gcand[tid];
     const float qinv = p.qinv[q];
-    // thread t = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
-    const f32x4 qfrag = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + (tid >> 5)) * 16 + ((tid >> 1) & 15)) * 64 + (tid & 1) * 32 + (q & 31)];
+    // thread t < 256 = (slice w, s, h) fetches its float4 of the raw query (prep_queries_kernel's layout)
+    f32x4 qfrag = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 256)
+        qfrag = reinterpret_cast<const f32x4 *>(p.a32)[((size_t)((q >> 5) * SCAN_WAVES + (tid >> 5)) * 16 + ((tid >> 1) & 15)) * 64 + (tid & 1) * 32 + (q & 31)];
     // Statistics (bench.py's byte accounting): a record per query that only this workgroup updates -- read here,
     // written back at the end with plain stores.  [They were three atomic adds on one shared record: 192 same-line
     // device-scope atomics per search, whose acknowledgements the kernel's end had to wait for.]  p.stats is the
@@ -2232,8 +2388,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     const bool in_lds = C <= FIN_ROUND;
     if (tid < C) lcand[tid] = first;
     if (in_lds)
-        for (int e = tid + MERGE_THREADS; e < C; e += MERGE_THREADS) lcand[e] = gcand[e];
-    qs[tid >> 5][(tid >> 1) & 15][tid & 1] = qfrag;
+        for (int e = tid + NT; e < C; e += NT) lcand[e] = gcand[e];
+    if (tid < 256) qs[tid >> 5][(tid >> 1) & 15][tid & 1] = qfrag;
     if (tid == 0) {
         s_nbest = 0;
         s_rescored = 0;
@@ -2241,11 +2397,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     }
     __syncthreads();
     if (tid == 0 && R == 1) p.count[q] = 0u;
+    FIN_T(1);   // first round trip done, candidates in LDS
 
-    // 1. k-th largest approximate score among the candidates
+    // 1. (a lower bound on) the k-th largest approximate score among the candidates
     uint32_t thr_ord = 0u;
     if (C > k) {
-        if (C <= MERGE_THREADS) {  // the usual case for k <= 24 (a few dozen candidates): rank by counting, one barrier
+        if (C <= 64) {  // a few dozen candidates (k <= 24): rank by counting in one wave, one barrier
             if (tid < C) {
                 const uint32_t mine = lcand[tid].x;
                 int rank = 0;
@@ -2253,48 +2410,78 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
                     const uint32_t o = lcand[i].x;
                     rank += (o > mine || (o == mine && i < tid)) ? 1 : 0;
                 }
-                if (rank == k - 1) s_kth = mine;
+                if (rank == k - 1) s_kth = mine & ~((1u << FIN_SKIP_BITS) - 1u);   // (the same value the searches below end with)
+            }
+            __syncthreads();
+        } else if (C < 64 * FIN_WAVE_PER) {   // (at most 1023: the packed 11-bit / 10-bit count fields below cannot wrap)
+            // Up to 1024 candidates (what a top-50 / top-100 search leaves since the scan sifts its staging buffer): ONE
+            // wave holds them all, 16 per lane, and runs the whole bit search (see below) without a barrier or an LDS
+            // word: per round seven ballots per register, scalar counts.  [Eight waves + a barrier per round: 0.9-1.3 us
+            // a round, 6.6 us for the five rounds of a typical top-100 search.]
+            if (wave == 0) {
+                uint32_t v[FIN_WAVE_PER];
+                uint32_t vmax = 0u, vmin = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < FIN_WAVE_PER; ++i) {
+                    const int e = tid + i * 64;
+                    v[i] = e < C ? lcand[e].x : 0u;
+                    if (e < C) {
+                        vmax = v[i] > vmax ? v[i] : vmax;
+                        vmin = v[i] < vmin ? v[i] : vmin;
+                    }
+                }
+                const int ln = tid & 63;
+                vmax = wave_reduce_u32(vmax, ln, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+                vmin = wave_reduce_u32(vmin, ln, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+                const uint32_t diff = vmax ^ vmin;
+                const int top0 = diff ? 32 - __builtin_clz(diff) : 0;
+                const int top = top0 > FIN_SKIP_BITS ? top0 : FIN_SKIP_BITS;
+                uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
+                // One bit per round: count the candidates >= ans | bit per LANE (a compare and an add-with-carry per
+                // register), one wave sum on the VALU (DPP + v_permlane swaps), keep the bit if k candidates reach it.
+                // [With one wave on its SIMD every instruction costs its full latency: three bits per round -- seven
+                // thresholds, three packed counters, three wave sums -- were ~230 instructions a round, 4.4 us for the
+                // five rounds of a typical top-100 search whatever the reduction was made of (ballot + s_bcnt1,
+                // ds_bpermute shuffles, DPP); one bit per round is ~36.]
+                for (int bit = top - 1; bit >= FIN_SKIP_BITS; --bit) {
+                    const uint32_t t = ans | (1u << bit);
+                    uint32_t c = 0u;
+#pragma unroll
+                    for (int i = 0; i < FIN_WAVE_PER; ++i)
+                        if (i * 64 < C) c += v[i] >= t ? 1u : 0u;   // (uniform branch; absent slots hold 0 < t)
+                    c = wave_reduce_u32(c, ln, [](uint32_t x, uint32_t y) { return x + y; });
+                    if ((int)c >= k) ans = t;
+                }
+                if (tid == 0) s_kth = ans;
             }
             __syncthreads();
         } else {
             // Search on the orderable score for the largest T with at least k candidates >= T, three bits per round:
-            // every thread counts its candidates (<= 16, in registers; beyond FIN_ROUND candidates it re-reads them)
-            // per value of the next three bits, the seven counts travel packed in two 64-bit words through a wave
-            // reduction and one barrier.  The candidates sit just above a common threshold, so their high bits
-            // agree: the search starts below the highest bit in which any two of them differ.
-            // (A radix select with an LDS histogram serialises here: a thousand atomics on ONE bin per pass; one
-            // bit per round was twenty barriers: 14 us of a top-100 search.)
-            constexpr int PER = FIN_ROUND / MERGE_THREADS;
+            // a wave counts its candidates (<= 8 per thread, in registers; beyond FIN_ROUND candidates it re-reads them)
+            // above each of the seven thresholds of the round with ballots -- the counts are scalars --, lane 0 posts
+            // them packed in two 64-bit words, one barrier, everybody adds the eight waves' words.  The candidates sit
+            // just above a common threshold, so their high bits agree: the search starts below the highest bit in which
+            // any two of them differ.
+            // [A radix select with an LDS histogram serialises here: a thousand atomics on ONE bin per pass.  One bit
+            // per round was twenty barriers.  Round 3 tallied digits per thread and reduced the packed counters with
+            // 24 64-bit shuffles per round: ~1.5 us a round; ranking 500 candidates by counting: 12 us.]
+            constexpr int PER = FIN_ROUND / NT;
             uint32_t v[PER];
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int e = tid + i * MERGE_THREADS;
+                const int e = tid + i * NT;
                 v[i] = (in_lds && e < C) ? lcand[e].x : 0u;
             }
-            auto block_sum2 = [&](unsigned long long &a, unsigned long long &b, int round) {  // sums over the workgroup
-                for (int o = 32; o > 0; o >>= 1) {
-                    a += (unsigned long long)__shfl_xor((long long)a, o);
-                    b += (unsigned long long)__shfl_xor((long long)b, o);
-                }
-                unsigned long long *slot = hist + (round & 1) * 8;
-                if ((tid & 63) == 0) {
-                    slot[(tid >> 6) * 2] = a;
-                    slot[(tid >> 6) * 2 + 1] = b;
-                }
-                __syncthreads();
-                a = slot[0] + slot[2] + slot[4] + slot[6];
-                b = slot[1] + slot[3] + slot[5] + slot[7];
-            };
             uint32_t vmax = 0u, vmin = 0xffffffffu;
             if (in_lds) {
 #pragma unroll
                 for (int i = 0; i < PER; ++i)
-                    if (tid + i * MERGE_THREADS < C) {
+                    if (tid + i * NT < C) {
                         vmax = v[i] > vmax ? v[i] : vmax;
                         vmin = v[i] < vmin ? v[i] : vmin;
                     }
             } else {
-                for (int e = tid; e < C; e += MERGE_THREADS) {
+                for (int e = tid; e < C; e += NT) {
                     const uint32_t o = gcand[e].x;
                     vmax = o > vmax ? o : vmax;
                     vmin = o < vmin ? o : vmin;
@@ -2306,12 +2493,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
                 vmin = b < vmin ? b : vmin;
             }
             if ((tid & 63) == 0) {
-                hist[16 + (tid >> 6)] = vmax;
-                hist[20 + (tid >> 6)] = vmin;
+                hist[32 + (tid >> 6)] = vmax;
+                hist[40 + (tid >> 6)] = vmin;
             }
             __syncthreads();
-            for (int i = 0; i < MERGE_THREADS / 64; ++i) {
-                const uint32_t a = (uint32_t)hist[16 + i], b = (uint32_t)hist[20 + i];
+            for (int i = 0; i < NT / 64; ++i) {
+                const uint32_t a = (uint32_t)hist[32 + i], b = (uint32_t)hist[40 + i];
                 vmax = a > vmax ? a : vmax;
                 vmin = b < vmin ? b : vmin;
             }
@@ -2320,97 +2507,65 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             const int top = top0 > FIN_SKIP_BITS ? top0 : FIN_SKIP_BITS;
             uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
             int round = 0;
-            auto search_bits = [&](int from_bit, int to_bit) {  // decides bits [to_bit, from_bit) of ans, three per round
-                for (int bit = from_bit; bit > to_bit; ++round) {
-                    const int nb = bit - to_bit >= 3 ? 3 : bit - to_bit, lo = bit - nb;  // this round decides bits [lo, bit)
-                    // digit d of a candidate: 0 if below ans | (1 << lo), else min((v - ans) >> lo, 7); packed counters:
-                    // a = #d==1 | #d==2 << 16 | #d==3 << 32 | #d==4 << 48, b = #d==5 | #d==6 << 16 | #d==7 << 32
-                    unsigned long long a = 0ull, b = 0ull;
-                    auto tally = [&](uint32_t x) {
-                        if (x >= ans) {
-                            const uint32_t d0 = (x - ans) >> lo;
-                            const uint32_t d = d0 > 7u ? 7u : d0;
-                            a += (d >= 1u && d <= 4u) ? 1ull << (16 * (d - 1u)) : 0ull;
-                            b += (d >= 5u) ? 1ull << (16 * (d - 5u)) : 0ull;
-                        }
-                    };
-                    if (in_lds) {
+            for (int bit = top; bit > FIN_SKIP_BITS; ++round) {  // decides bits [FIN_SKIP_BITS, top) of ans, three per round
+                const int nb = bit - FIN_SKIP_BITS >= 3 ? 3 : bit - FIN_SKIP_BITS, lo = bit - nb;  // this round: bits [lo, bit)
+                // cnt[jj-1] = candidates of this wave >= ans + (jj << lo), jj = 1 .. 7 (absent slots hold 0 < ans)
+                uint32_t cnt[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                auto tally = [&](uint32_t x) {
 #pragma unroll
-                        for (int i = 0; i < PER; ++i) tally(v[i]);
-                    } else {
-                        for (int e = tid; e < C; e += MERGE_THREADS) tally(gcand[e].x);
-                    }
-                    block_sum2(a, b, round);
-                    int at_least = 0;  // candidates whose digit is >= j, j = 7 .. 1
-                    uint32_t pick = 0u;
-                    for (int j = 7; j >= 1; --j) {
-                        at_least += (int)(((j >= 5 ? b >> (16 * (j - 5)) : a >> (16 * (j - 1)))) & 0xffffull);
-                        if (pick == 0u && at_least >= k && j < (1 << nb)) pick = (uint32_t)j;
-                    }
-                    ans |= pick << lo;
-                    bit = lo;
-                }
-            };
-            search_bits(top, FIN_SKIP_BITS);
-            // ans = the k-th value with its low FIN_SKIP_BITS bits cleared: the k-th value itself is one of the
-            // candidates in [ans, ans + 2^FIN_SKIP_BITS).  Count what lies above that bucket, collect the bucket (in
-            // `surv`, free until step 2) and rank it by counting.
-            if (tid == 0) s_nsurv = 0;
-            __syncthreads();
-            const uint32_t hi = ans + (1u << FIN_SKIP_BITS);   // (scores <= 1: ord <= 0xbf800000, no wrap)
-            unsigned long long above = 0ull, unused = 0ull;
-            auto sift = [&](uint32_t x) {
-                if (x >= hi) {
-                    ++above;
-                } else if (x >= ans && x != 0u) {
-                    const int slot = atomicAdd(&s_nsurv, 1);
-                    if (slot < FIN_ROUND) surv[slot] = x;
-                }
-            };
-            if (in_lds) {
+                    for (int jj = 1; jj <= 7; ++jj)
+                        cnt[jj - 1] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(x >= ans + ((uint32_t)jj << lo)));
+                };
+                if (in_lds) {
 #pragma unroll
-                for (int i = 0; i < PER; ++i) sift(v[i]);
-            } else {
-                for (int e = tid; e < C; e += MERGE_THREADS) sift(gcand[e].x);
-            }
-            block_sum2(above, unused, round++);   // (its barrier also publishes the bucket)
-            const int nbk = s_nsurv, need = k - (int)above;   // the bucket's need-th largest is the answer
-            __syncthreads();                                  // (everybody has read s_nsurv before it is reused)
-            if (nbk <= 2 * MERGE_THREADS && need >= 1 && need <= nbk) {
-                for (int e = tid; e < nbk; e += MERGE_THREADS) {
-                    const uint32_t mine = surv[e];
-                    int rank = 0;
-                    for (int i = 0; i < nbk; ++i) {
-                        const uint32_t o = surv[i];
-                        rank += (o > mine || (o == mine && i < e)) ? 1 : 0;
-                    }
-                    if (rank == need - 1) s_kth = mine;
+                    for (int i = 0; i < PER; ++i) tally(v[i]);
+                } else {
+                    for (int e0 = 0; e0 < C; e0 += NT) tally(e0 + tid < C ? gcand[e0 + tid].x : 0u);   // (uniform trip count)
+                }
+                unsigned long long *slot = hist + (round & 1) * 16;
+                if ((tid & 63) == 0) {
+                    slot[(tid >> 6) * 2] = (unsigned long long)cnt[0] | ((unsigned long long)cnt[1] << 16) |
+                                           ((unsigned long long)cnt[2] << 32) | ((unsigned long long)cnt[3] << 48);
+                    slot[(tid >> 6) * 2 + 1] = (unsigned long long)cnt[4] | ((unsigned long long)cnt[5] << 16) |
+                                               ((unsigned long long)cnt[6] << 32);
                 }
                 __syncthreads();
-                ans = s_kth;
-            } else {
-                search_bits(FIN_SKIP_BITS, 0);   // thousands of candidates in one bucket (duplicated rows): finish bit by bit
+                unsigned long long a = 0ull, b = 0ull;   // (a wave's count <= 4096 and the total <= cap < 65536: 16 bits each)
+#pragma unroll
+                for (int wv = 0; wv < NT / 64; ++wv) {
+                    a += slot[2 * wv];
+                    b += slot[2 * wv + 1];
+                }
+                uint32_t pick = 0u;
+                for (int jj = 7; jj >= 1; --jj) {   // the counts fall with jj: the largest digit still reached by k candidates
+                    const int at_least = (int)(((jj >= 5 ? b >> (16 * (jj - 5)) : a >> (16 * (jj - 1)))) & 0xffffull);
+                    if (pick == 0u && at_least >= k && jj < (1 << nb)) pick = (uint32_t)jj;
+                }
+                ans |= pick << lo;
+                bit = lo;
             }
+            // ans = the k-th value with its low FIN_SKIP_BITS bits cleared (a lower bound on it)
             if (tid == 0) s_kth = ans;
             __syncthreads();
         }
         thr_ord = f2ord(ord2f(s_kth) - 2.f * PF_DELTA);
     }
+    FIN_T(2);   // k-th approximate score known
 
-    // 2. survivors -> exact scores, 8 lanes per row, in rounds of FIN_ROUND candidates
-    const int grp = tid >> 3, sub = tid & 7;  // 32 rows per sweep; lane `sub` = K slice (the scan's wave w)
+    // 2. survivors -> exact scores, 8 lanes per row (64 rows per sweep), in rounds of FIN_ROUND candidates
+    const int grp = tid >> 3, sub = tid & 7;  // lane `sub` = K slice (the scan's wave w)
     for (int r0 = 0; r0 < C; r0 += FIN_ROUND) {
         const int rn = (C - r0) < FIN_ROUND ? (C - r0) : FIN_ROUND;
         if (tid == 0) s_nsurv = 0;
         __syncthreads();
-        for (int e = tid; e < rn; e += MERGE_THREADS) {
+        for (int e = tid; e < rn; e += NT) {
             const uint2 ce = in_lds ? lcand[e] : gcand[r0 + e];
             // (several blocks per query: block r rescores the candidates whose list position is r mod R)
             if (ce.x >= thr_ord && (((r0 + e) & (R - 1)) == rpart)) surv[atomicAdd(&s_nsurv, 1)] = ce.y;
         }
         __syncthreads();
         const int ns = s_nsurv;
-        for (int e0 = 0; e0 < ns; e0 += 32) {
+        for (int e0 = 0; e0 < ns; e0 += NT / 8) {
             const int e = e0 + grp;
             const bool live = e < ns;
             const uint32_t row = live ? surv[e] : 0u;
@@ -2445,11 +2600,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         if (tid == 0) s_rescored += ns;
         if (r0 + FIN_ROUND < C && s_nbest > k) {  // more rounds follow: keep only the running top-k
             const int B = s_nbest;
-            uint64_t mine[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
-            int64_t mine_id[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
-            int rank[(FIN_BEST + MERGE_THREADS - 1) / MERGE_THREADS];
+            uint64_t mine[(FIN_BEST + NT - 1) / NT];
+            int64_t mine_id[(FIN_BEST + NT - 1) / NT];
+            int rank[(FIN_BEST + NT - 1) / NT];
             int n_mine = 0;
-            for (int e = tid; e < B; e += MERGE_THREADS) {
+            for (int e = tid; e < B; e += NT) {
                 const uint64_t m = best[e];
                 int rk = 0;
                 for (int i = 0; i < B; ++i) rk += (best[i] > m) ? 1 : 0;
@@ -2468,21 +2623,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
         }
     }
 
+    FIN_T(3);   // survivors rescored
     // 3. rank by counting among the exact keys
     int B = s_nbest;
     unsigned long long rescored_all = (unsigned long long)s_rescored;
     if (R > 1) {
-        // this block's own top-k (no other key of its share can be in the query's top-k) -> global scratch; the block
-        // of the query that finishes LAST gathers the R lists and ranks them.  Nobody waits for anybody.
+        // this block's own best keys (at most k of them can be in the query's top-k; its share is rarely larger) ->
+        // global scratch; the block of the query that finishes LAST gathers the R lists and ranks them.  Nobody waits
+        // for anybody.
         uint64_t *const xk = p.xkeys + ((size_t)q * R + rpart) * k;
         int64_t *const xi = p.xids + ((size_t)q * R + rpart) * k;
-        for (int e = tid; e < B; e += MERGE_THREADS) {
-            const uint64_t mine = best[e];
-            int rank = 0;
-            for (int i = 0; i < B; ++i) rank += (best[i] > mine) ? 1 : 0;
-            if (rank < k) {
-                xk[rank] = mine;
-                xi[rank] = best_id[e];
+        if (B <= k) {   // (uniform) the usual case: everything, unsorted
+            for (int e = tid; e < B; e += NT) {
+                xk[e] = best[e];
+                xi[e] = best_id[e];
+            }
+        } else {
+            for (int e = tid; e < B; e += NT) {
+                const uint64_t mine = best[e];
+                int rank = 0;
+                for (int i = 0; i < B; ++i) rank += (best[i] > mine) ? 1 : 0;
+                if (rank < k) {
+                    xk[rank] = mine;
+                    xi[rank] = best_id[e];
+                }
             }
         }
         if (tid == 0) p.xcount[(size_t)q * R + rpart] = make_uint2((uint32_t)(B < k ? B : k), (uint32_t)s_rescored);
@@ -2499,19 +2663,35 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             }
         }
         __syncthreads();
+        FIN_T(4);   // own list written, ticket drawn
         if (!s_last) return;
-        int base = 0;
+        // gather: the R counts and the first NT / R slots of every list are requested together (one round trip; a list
+        // longer than that -- k > 64 with four lists -- is completed behind it)
+        const int per = NT / R, rr_mine = tid / per, e_mine = tid % per;   // (R is 4 or 8: NT / R = 128 or 64 slots per list)
+        const uint2 cr_mine = p.xcount[(size_t)q * R + rr_mine];
+        uint64_t k_mine = 0ull;
+        int64_t i_mine = -1;
+        if (e_mine < k) {   // (within the list's k slots; stale beyond its count, masked below)
+            k_mine = p.xkeys[((size_t)q * R + rr_mine) * k + e_mine];
+            i_mine = p.xids[((size_t)q * R + rr_mine) * k + e_mine];
+        }
+        if (e_mine == 0) hist[48 + rr_mine] = ((unsigned long long)cr_mine.y << 32) | cr_mine.x;
+        __syncthreads();
+        int base = 0, base_mine = 0;
         rescored_all = 0ull;
-        for (int rr = 0; rr < R; ++rr) {  // (R <= 8 lists of <= k keys each: <= 1024 keys)
-            const uint2 cr = p.xcount[(size_t)q * R + rr];
-            const uint64_t *sk = p.xkeys + ((size_t)q * R + rr) * k;
-            const int64_t *si = p.xids + ((size_t)q * R + rr) * k;
-            for (int e = tid; e < (int)cr.x; e += MERGE_THREADS) {
-                best[base + e] = sk[e];
-                best_id[base + e] = si[e];
-            }
-            base += (int)cr.x;
-            rescored_all += cr.y;
+        for (int rr = 0; rr < R; ++rr) {
+            const unsigned long long c2 = hist[48 + rr];
+            if (rr == rr_mine) base_mine = base;
+            base += (int)(uint32_t)c2;
+            rescored_all += c2 >> 32;
+        }
+        if (e_mine < (int)cr_mine.x) {
+            best[base_mine + e_mine] = k_mine;
+            best_id[base_mine + e_mine] = i_mine;
+        }
+        for (int e = e_mine + per; e < (int)cr_mine.x; e += per) {
+            best[base_mine + e] = p.xkeys[((size_t)q * R + rr_mine) * k + e];
+            best_id[base_mine + e] = p.xids[((size_t)q * R + rr_mine) * k + e];
         }
         B = base;
         if (tid == 0) {
@@ -2524,9 +2704,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             }
         }
         __syncthreads();
+        FIN_T(5);   // the R lists gathered
     }
     const int count = B < k ? B : k;
-    for (int e = tid; e < B; e += MERGE_THREADS) {
+    for (int e = tid; e < B; e += NT) {
         const uint64_t mine = best[e];
         int rank = 0;
         for (int i = 0; i < B; ++i) rank += (best[i] > mine) ? 1 : 0;
@@ -2535,7 +2716,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             p.out_ids[(size_t)q * k + rank] = best_id[e];
         }
     }
-    for (int r = count + tid; r < k; r += MERGE_THREADS) {
+    for (int r = count + tid; r < k; r += NT) {
         p.out_scores[(size_t)q * k + r] = __uint_as_float(0x7fc00000u);
         p.out_ids[(size_t)q * k + r] = -1;
     }
@@ -2547,6 +2728,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             if (q == 0) stat[2] = stat_old[2] + 1ull;
         }
     }
+    FIN_T(6);
+    if (p.trace && (int)blockIdx.x < R && threadIdx.x == 0) {
+        p.trace[rpart * 16 + 8] = (unsigned long long)C;
+        p.trace[rpart * 16 + 9] = (unsigned long long)s_rescored;
+    }
+#undef FIN_T
 }
 
 // number of positions i in [0, n) whose id is not greater than its predecessor's (ids[-1] = prev)

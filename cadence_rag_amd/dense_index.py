@@ -184,6 +184,23 @@ class DenseIndex:
             d_out_ids.data_ptr(), d_out_scores.data_ptr(), d_out_counts.data_ptr(),
             ctypes.c_void_p(stream)), "crag_index_search_async")
 
+    def search_pipelined(self, d_queries, k: int, d_out_ids, d_out_scores, d_out_counts,
+                         d_row_mask=None, mask_stride: int = 0, stream: int = 0, inputs_ready: bool = False) -> None:
+        """Throughput form for a run of INDEPENDENT searches issued from one stream (crag_index_search_pipelined):
+        consecutive calls alternate between two streams of the index's own, so search i + 1's preparation and scan run
+        beside search i's selection.  The outputs are defined on `stream` only behind join(stream).  inputs_ready: the
+        queries / mask are complete in memory now (no event orders the internal stream behind `stream`)."""
+        nq = int(d_queries.shape[0])
+        _native.check(self._lib.crag_index_search_pipelined(
+            self._h, d_queries.data_ptr(), nq, int(k),
+            None if d_row_mask is None else d_row_mask.data_ptr(), int(mask_stride),
+            d_out_ids.data_ptr(), d_out_scores.data_ptr(), d_out_counts.data_ptr(),
+            ctypes.c_void_p(stream), 1 if inputs_ready else 0), "crag_index_search_pipelined")
+
+    def join(self, stream: int = 0) -> None:
+        """Make `stream` wait for every pipelined search issued so far (does not block the host)."""
+        _native.check(self._lib.crag_index_join(self._h, ctypes.c_void_p(stream)), "crag_index_join")
+
     # -- profiling / reporting -------------------------------------------------------------
     def profile_enable(self, every: int = 1) -> None:
         """Record HIP events around the scan/merge kernels of every `every`-th search (0 = off)."""
@@ -211,6 +228,12 @@ class DenseIndex:
         _native.check(self._lib.crag_index_prefilter_stats(self._h, ctypes.byref(a), ctypes.byref(b),
                                                            ctypes.byref(c)), "prefilter_stats")
         return {"searches": a.value, "candidates": b.value, "rescored_rows": c.value}
+
+    def phase_trace(self):
+        """Developer probe (CRAG_PHASE_TRACE=1 when the index was created): see crag_index_phase_trace."""
+        buf = (ctypes.c_uint64 * 128)()
+        _native.check(self._lib.crag_index_phase_trace(self._h, buf), "phase_trace")
+        return [int(v) for v in buf]
 
     def prefilter_row_bytes(self) -> int:
         """Bytes of one corpus row the prefilter scan streams (2 KiB with the fp16 mirror, 4 KiB without, 0 = off)."""
@@ -248,11 +271,20 @@ class ResultRecord:
     (ids int64 [nq,k], scores fp32 [nq,k], counts int32 [nq]) laid out as crag_merge_topk_packed
     expects."""
 
-    def __init__(self, nq: int, k: int, device) -> None:
-        lib = _native.load()
+    @staticmethod
+    def record_bytes(nq: int, k: int) -> int:
+        return int(_native.load().crag_result_record_bytes(int(nq), int(k)))
+
+    def __init__(self, nq: int, k: int, device, buf=None) -> None:
+        """buf: an existing uint8 tensor of record_bytes(nq, k) bytes to lay the record over (this rank's slot of an
+        all-gather buffer: the collective then runs in place); default: a buffer of its own."""
         self.nq, self.k = int(nq), int(k)
-        self.nbytes = int(lib.crag_result_record_bytes(self.nq, self.k))
-        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.nbytes = self.record_bytes(self.nq, self.k)
+        if buf is None:
+            buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        if buf.dtype != torch.uint8 or buf.numel() != self.nbytes or not buf.is_contiguous() or buf.data_ptr() % 8:
+            raise ValueError("a ResultRecord needs a contiguous, 8-byte aligned uint8 buffer of record_bytes(nq, k) bytes")
+        self.buf = buf
         a, b = self.nq * self.k * 8, self.nq * self.k * 12
         self.ids = self.buf[:a].view(torch.int64).view(self.nq, self.k)
         self.scores = self.buf[a:b].view(torch.float32).view(self.nq, self.k)

@@ -13,19 +13,27 @@ from . import _native
 DEFAULT_RRF_K = 60
 
 
+_ext_streams: dict = {}
+
+
 def _on_stream(stream: int, device):
     """Context in which torch allocates, uploads and frees on the caller's HIP stream, so that every
     temporary of a call is ordered with the kernels the C ABI enqueues on that same stream (stream 0 =
     the null stream, which is also torch's default current stream)."""
-    return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device) if stream else
-                             torch.cuda.default_stream(device))
+    key = (int(stream), str(device))
+    ext = _ext_streams.get(key)
+    if ext is None:   # (wrapping a raw stream handle costs ~10 us: once per stream)
+        ext = _ext_streams[key] = (torch.cuda.ExternalStream(int(stream), device=device) if stream else
+                                   torch.cuda.default_stream(device))
+    return torch.cuda.stream(ext)
 
 
 def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf_k: int = DEFAULT_RRF_K,
-             stream: int = 0) -> Dict[str, torch.Tensor]:
+             stream: int = 0, out: "Dict[str, torch.Tensor] | None" = None) -> Dict[str, torch.Tensor]:
     """lanes: [(ids int64 [nq, width] CUDA, counts int32 [nq] CUDA), ...] in lane order (the
     reference's order is bm25, tech_tokens, dense).  Returns ids [nq, out_k] (-1 pad), scores fp64,
-    lane-hit masks (bit l = lane l), counts."""
+    lane-hit masks (bit l = lane l), counts.  `out`: a dict of that shape to write into (a caller that fuses the
+    same batch shape again and again saves four allocations per call)."""
     lib = _native.load()
     n = len(lanes)
     nq = int(lanes[0][0].shape[0])
@@ -35,12 +43,13 @@ def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf
         ids_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(t.data_ptr()) for t, _ in keep])
         cnt_arr = (ctypes.c_void_p * n)(*[ctypes.c_void_p(c.data_ptr()) for _, c in keep])
         width = (ctypes.c_int * n)(*[int(t.shape[1]) for t, _ in keep])
-        out = {
-            "ids": torch.empty(nq, out_k, dtype=torch.int64, device=dev),
-            "scores": torch.empty(nq, out_k, dtype=torch.float64, device=dev),
-            "lanes": torch.empty(nq, out_k, dtype=torch.int32, device=dev),
-            "counts": torch.empty(nq, dtype=torch.int32, device=dev),
-        }
+        if out is None:
+            out = {
+                "ids": torch.empty(nq, out_k, dtype=torch.int64, device=dev),
+                "scores": torch.empty(nq, out_k, dtype=torch.float64, device=dev),
+                "lanes": torch.empty(nq, out_k, dtype=torch.int32, device=dev),
+                "counts": torch.empty(nq, dtype=torch.int32, device=dev),
+            }
         _native.check(lib.crag_rrf_fuse(n, ids_arr, cnt_arr, width, nq, int(rrf_k), int(out_k),
                                         out["ids"].data_ptr(), out["scores"].data_ptr(), out["lanes"].data_ptr(),
                                         out["counts"].data_ptr(), ctypes.c_void_p(stream)), "crag_rrf_fuse")
@@ -51,6 +60,7 @@ def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf
 # exact-token lane
 # ------------------------------------------------------------------------------------------------
 import hashlib  # noqa: E402
+from array import array  # noqa: E402
 
 import numpy as np  # noqa: E402
 
@@ -60,6 +70,26 @@ MAX_QUERY_TOKENS = 32
 def token_hash(token: str) -> int:
     """64-bit hash of the EXACT token string (the SQL `&&` compares text[] elements exactly)."""
     return int.from_bytes(hashlib.blake2b(token.encode("utf-8"), digest_size=8).digest(), "little")
+
+
+_HASH_CACHE_MAX = 1 << 18
+_hash_cache: dict = {}   # token string -> hash.  Query tokens repeat (ticket ids, error names, versions): a lookup is
+                         # ~30 ns, blake2b + int.from_bytes ~1 us.  Dropped wholesale when it reaches the cap.
+
+
+def _hashes(token_lists) -> "array":
+    """All tokens of all lists, hashed, flat, in list order (array('Q'))."""
+    cache = _hash_cache
+    try:
+        return array("Q", [cache[t] for toks in token_lists for t in toks])
+    except KeyError:
+        if len(cache) > _HASH_CACHE_MAX:
+            cache.clear()
+        for toks in token_lists:
+            for t in toks:
+                if t not in cache:
+                    cache[t] = token_hash(t)
+        return array("Q", [cache[t] for toks in token_lists for t in toks])
 
 
 class TechTokenIndex:
@@ -86,6 +116,7 @@ class TechTokenIndex:
         self.row_ptr = torch.from_numpy(row_ptr).to(device)
         self.tokens = torch.from_numpy(toks.view(np.int64)).to(device)
         self.ids = torch.from_numpy(ids).to(device)
+        self._arange = np.arange(64 * MAX_QUERY_TOKENS)
         self._bitmaps: dict = {}   # per stream: two streams sharing one index must not share scratch
         self._pinned: dict = {}    # per stream: ring of pinned upload buffers for the query tokens
         self._rank_of_id = None
@@ -93,50 +124,73 @@ class TechTokenIndex:
         self._row_tokens = [frozenset(t) for t in row_tokens] if verify else None
         self._pos_of_id = None
 
+    _QT_BYTES = 64 * MAX_QUERY_TOKENS * 8   # the query-token block of an upload slot; the 64 counts (int32) follow
+
+    def _slot(self, stream: int):
+        """Next upload slot of the stream's ring of four: ONE pinned host buffer (query-token hashes [64, 32] int64 |
+        token counts [64] int32), its device twin, the per-k output tensors and the event of the slot's last upload.
+        Everything is allocated once per stream: a call allocates nothing and uploads with ONE copy.  [Round 3: four
+        torch.empty on the device per call, two copies, blake2b per token: 156 us of host time around 22 us of
+        kernels.]"""
+        ring = self._pinned.setdefault(stream, {"next": 0, "slots": []})
+        if len(ring["slots"]) < 4:
+            nbytes = self._QT_BYTES + 64 * 4
+            host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            hnp = host.numpy()
+            ring["slots"].append({
+                "host": host, "dev": torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                "h_qt": hnp[:self._QT_BYTES].view(np.uint64).reshape(64, MAX_QUERY_TOKENS),
+                "h_qn": hnp[self._QT_BYTES:].view(np.int32), "done": torch.cuda.Event(), "out": {}})
+        slot = ring["slots"][ring["next"] % len(ring["slots"])]
+        ring["next"] += 1
+        return slot
+
     def _pass(self, token_lists, k: int, row_mask, mask_stride: int, stream: int):
-        """One launch of the lane: at most MAX_QUERY_TOKENS tokens per query."""
+        """One launch of the lane: at most MAX_QUERY_TOKENS tokens per query.  The returned tensors belong to the
+        stream's upload ring: they are valid until the fourth following call on the same stream."""
         nq = len(token_lists)
-        qt = np.zeros((nq, MAX_QUERY_TOKENS), dtype=np.uint64)
-        qn = np.zeros(nq, dtype=np.int32)
-        for i, toks in enumerate(token_lists):
-            qt[i, :len(toks)] = [token_hash(t) for t in toks]
-            qn[i] = len(toks)
+        if nq > 64:
+            raise ValueError("the exact-token lane takes at most 64 queries per call")
+        lens = list(map(len, token_lists))
+        flat = _hashes(token_lists)
         words = max((self.n + 63) // 64, 1)
         with _on_stream(stream, self.device):
             # uploads from a small ring of pinned buffers: a copy from pageable memory blocks the host until the
             # stream has reached it, i.e. until the dense scan enqueued in front of it has finished -- host and GPU
             # in lockstep, one step at a time
-            ring = self._pinned.setdefault(stream, {"next": 0, "slots": []})
-            if len(ring["slots"]) < 4:
-                ring["slots"].append((torch.empty(64, MAX_QUERY_TOKENS, dtype=torch.int64).pin_memory(),
-                                      torch.empty(64, dtype=torch.int32).pin_memory(), torch.cuda.Event()))
-            h_qt, h_qn, done = ring["slots"][ring["next"] % len(ring["slots"])]
-            ring["next"] += 1
-            if nq > 64:
-                raise ValueError("the exact-token lane takes at most 64 queries per call")
-            done.synchronize()          # the copy that last used this slot has left the host buffer
-            h_qt.numpy()[:nq] = qt.view(np.int64)
-            h_qn.numpy()[:nq] = qn
-            d_qt = torch.empty(nq, MAX_QUERY_TOKENS, dtype=torch.int64, device=self.device)
-            d_qn = torch.empty(nq, dtype=torch.int32, device=self.device)
-            d_qt.copy_(h_qt[:nq], non_blocking=True)
-            d_qn.copy_(h_qn[:nq], non_blocking=True)
-            done.record()
+            slot = self._slot(stream)
+            slot["done"].synchronize()          # the copy that last used this slot has left the host buffer
+            h_qt, h_qn = slot["h_qt"], slot["h_qn"]
+            h_qn[:nq] = lens
+            if len(flat):                       # (only the first lens[q] tokens of a query are ever read)
+                fa = np.frombuffer(flat, dtype=np.uint64)
+                if lens.count(lens[0]) == nq:
+                    h_qt[:nq, :lens[0]] = fa.reshape(nq, lens[0])
+                else:
+                    la = h_qn[:nq]
+                    ar = self._arange
+                    h_qt[np.repeat(ar[:nq], la), ar[:len(flat)] - np.repeat(np.cumsum(la) - la, la)] = fa
+            slot["dev"].copy_(slot["host"], non_blocking=True)
+            slot["done"].record()
+            d_base = slot["dev"].data_ptr()
             bitmap = self._bitmaps.get(stream)
             if bitmap is None or bitmap.numel() < nq * words:
                 bitmap = self._bitmaps[stream] = torch.empty(nq * words, dtype=torch.int64, device=self.device)
-            out_ids = torch.empty(nq, k, dtype=torch.int64, device=self.device)
-            out_ct = torch.empty(nq, dtype=torch.int32, device=self.device)
+            outs = slot["out"].get(k)
+            if outs is None:
+                outs = slot["out"][k] = (torch.empty(64, k, dtype=torch.int64, device=self.device),
+                                         torch.empty(64, dtype=torch.int32, device=self.device))
+            out_ids, out_ct = outs[0][:nq], outs[1][:nq]
             lib = _native.load()
             _native.check(lib.crag_tech_lane(self.order.data_ptr(), self.row_ptr.data_ptr(), self.tokens.data_ptr(),
-                                             self.ids.data_ptr(), self.n, d_qt.data_ptr(), d_qn.data_ptr(), nq,
+                                             self.ids.data_ptr(), self.n, d_base, d_base + self._QT_BYTES, nq,
                                              int(k), None if row_mask is None else row_mask.data_ptr(),
                                              int(mask_stride), bitmap.data_ptr(), out_ids.data_ptr(),
                                              out_ct.data_ptr(), ctypes.c_void_p(stream)), "crag_tech_lane")
         return out_ids, out_ct
 
     def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0,
-               verify: "bool | None" = None):
+               verify: "bool | None" = None, borrow: bool = False):
         """verify (default: whatever the index was built with): check the returned rows' token STRINGS on the host.
         That check copies ids and counts to the host and therefore SYNCHRONISES the caller's stream; pass
         verify=False on a batched, stream-ordered path (HybridSearcher does) — the lane then differs from the SQL
@@ -145,6 +199,9 @@ class TechTokenIndex:
         number of tokens per query: the SQL `tech_tokens && :tokens` has no bound either.  The kernel takes 32
         tokens per query and launch; a longer list (a pasted log with many URLs / hashes) runs in several
         passes whose hits are merged in the lane's static order.
+        borrow=True returns the lane's own ring buffers (valid until the fourth following call on the same stream:
+        what a caller that consumes them at once wants -- HybridSearcher feeds them to the fusion kernel); the
+        default returns copies.
         Returns (ids int64 [nq, k] -1 padded, counts int32 [nq]) CUDA tensors, best (most recent) first."""
         lists = [list(dict.fromkeys(toks)) for toks in query_token_lists]  # distinct, first occurrence kept
         check = (self._row_tokens is not None) if verify is None else (bool(verify) and self._row_tokens is not None)
@@ -153,6 +210,9 @@ class TechTokenIndex:
             out_ids, out_ct = self._pass(lists, k, row_mask, mask_stride, stream)
             if check:
                 out_ids, out_ct = self._verified(lists, k, out_ids, out_ct, row_mask, mask_stride, stream)
+            if not borrow:
+                with _on_stream(stream, self.device):
+                    out_ids, out_ct = out_ids.clone(), out_ct.clone()
             return out_ids, out_ct
         if self._rank_of_id is None:
             order = self.order.cpu().numpy()
@@ -236,6 +296,7 @@ class HybridSearcher:
         self.overlap_lanes = bool(overlap_lanes)
         self.dense_k, self.tech_k, self.rrf_k = int(dense_k), int(tech_k), int(rrf_k)
         self._dense_out: dict = {}  # per (stream, batch size): results of calls on different streams stay apart
+        self._fused_out: dict = {}  # per (stream, batch size, out_k): the fusion's outputs
         self._side: dict = {}       # per caller stream: (side stream, fork event, join event)
 
     def search(self, query_vectors: torch.Tensor, query_token_lists=None, bm25=None, *, out_k: int = 0,
@@ -245,8 +306,8 @@ class HybridSearcher:
         position (uint8 CUDA), shared (mask_stride 0) or per query.  Returns rrf_fuse's dict plus the dense
         lane itself ("dense_ids", "dense_scores", "dense_counts").  Everything is enqueued on `stream` (token
         lists longer than 32 tokens and verify_tokens=True are the exceptions: both visit the host); the
-        dense buffers are reused by the next call with the same stream and batch size (the returned tensors
-        are valid until then), and the caller orders `query_vectors` / `row_mask` / `bm25` with `stream`."""
+        dense and fused buffers are reused by the next call with the same stream and batch shape (the returned
+        tensors are valid until then), and the caller orders `query_vectors` / `row_mask` / `bm25` with `stream`."""
         nq = int(query_vectors.shape[0])
         dev = query_vectors.device
         if (stream, nq) not in self._dense_out:
@@ -271,7 +332,7 @@ class HybridSearcher:
         if overlap:  # the dense scan is enqueued first: the host's share of the token lane runs under it
             side.wait_event(fork)
             tech_lane = self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
-                                         stream=side.cuda_stream, verify=False)
+                                         stream=side.cuda_stream, verify=False, borrow=True)
             join.record(side)
         lanes = []
         if bm25 is not None:
@@ -282,9 +343,18 @@ class HybridSearcher:
             lanes.append(tech_lane)
         elif use_tech:
             lanes.append(self.tech.search(query_token_lists, self.tech_k, row_mask=row_mask, mask_stride=mask_stride,
-                                          stream=stream, verify=self.verify_tokens))
+                                          stream=stream, verify=self.verify_tokens, borrow=True))
         lanes.append((d_ids, d_ct))
         width = sum(int(t.shape[1]) for t, _ in lanes)
-        out = rrf_fuse(lanes, out_k=out_k or width, rrf_k=self.rrf_k, stream=stream)
+        ok = out_k or width
+        fused = self._fused_out.get((stream, nq, ok))
+        if fused is None:   # like the dense buffers: reused by the next call with the same stream and batch shape
+            with _on_stream(stream, dev):
+                fused = self._fused_out[(stream, nq, ok)] = {
+                    "ids": torch.empty(nq, ok, dtype=torch.int64, device=dev),
+                    "scores": torch.empty(nq, ok, dtype=torch.float64, device=dev),
+                    "lanes": torch.empty(nq, ok, dtype=torch.int32, device=dev),
+                    "counts": torch.empty(nq, dtype=torch.int32, device=dev)}
+        out = dict(rrf_fuse(lanes, out_k=ok, rrf_k=self.rrf_k, stream=stream, out=fused))
         out["dense_ids"], out["dense_scores"], out["dense_counts"] = d_ids, d_sc, d_ct
         return out

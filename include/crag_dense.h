@@ -113,6 +113,24 @@ int crag_index_search_async(crag_index *ix, const float *d_queries, int nq, int 
                             const uint8_t *d_row_mask, int64_t mask_stride, int64_t *d_out_ids,
                             float *d_out_scores, int32_t *d_out_counts, void *stream);
 
+/* Throughput form of crag_index_search_async for ONE caller stream that issues a run of INDEPENDENT searches (a
+ * batch job: the eval harness, bulk re-ranking, bench.py): consecutive calls alternate between two streams the index
+ * owns -- each with its own workspace --, so that the query preparation and the scan of search i + 1 run beside the
+ * selection of search i; an in-order stream leaves the chip idle during those small kernels (14 of 48 us per search
+ * at 100 000 rows x 64 queries).  What the caller gives up is the stream order between a search and what follows:
+ *   * the OUTPUTS of a call are defined on `stream` only behind crag_index_join(ix, stream) (which makes `stream`
+ *     wait for every pipelined search issued so far; it does not block the host);
+ *   * flags & CRAG_PIPE_INPUTS_READY: the caller states that queries / row_mask are complete in memory when the call
+ *     is made (resident inputs); without it the library orders its internal stream behind everything enqueued on
+ *     `stream` so far (one event per call).
+ * Results are the same bits as crag_index_search_async's.  Same reference call sites as crag_index_search
+ * (retrieve.py:339-353, 369-388); the reference itself runs one query per request and has no counterpart. */
+#define CRAG_PIPE_INPUTS_READY 1
+int crag_index_search_pipelined(crag_index *ix, const float *d_queries, int nq, int k,
+                                const uint8_t *d_row_mask, int64_t mask_stride, int64_t *d_out_ids,
+                                float *d_out_scores, int32_t *d_out_counts, void *stream, int flags);
+int crag_index_join(crag_index *ix, void *stream);
+
 /* Merge per-shard results (the multi-GPU exchange step: each rank's [nq, k] top-k after an
  * RCCL all-gather) into the global top-k.  All pointers DEVICE.
  *   d_ids/d_scores/d_counts  [n_lists, nq, k] / [n_lists, nq, k] / [n_lists, nq]
@@ -175,6 +193,13 @@ int crag_index_profile_read_ex(crag_index *ix, int64_t *n_launches, double *scan
  * candidates = rows that passed the proven-bound filter, rescored_rows = rows re-read (4 KiB each) for the
  * exact fp32 score.  Synchronises the device. */
 int crag_index_prefilter_stats(crag_index *ix, int64_t *searches, int64_t *candidates, int64_t *rescored_rows);
+
+/* Developer probe (index created with CRAG_PHASE_TRACE=1 in the environment, else CRAG_EINVAL): 128 words written by
+ * the selection blocks of query 0 of the most recent prefilter search -- [block r of the query][16]: 100 MHz
+ * timestamps at the phase boundaries (0 start, 1 candidates loaded, 2 k-th approximate score, 3 survivors rescored,
+ * 4 own list written + ticket, 5 lists gathered, 6 end), [8] candidates, [9] rows this block rescored.
+ * Synchronises the device.  No reference counterpart (measurement only). */
+int crag_index_phase_trace(crag_index *ix, uint64_t *out128);
 
 /* Name of the scan kernel the most recent search on this index launched ("crag::scan_pipe_kernel", ...),
  * as rocprofv3 prints it; "" before the first search.  For bench.py's roofline object. */

@@ -100,3 +100,21 @@ def random_short_token_lists(rng, vocab_size, shapes=("1x16", "1x32", "2x16")):
         b, l = (int(x) for x in shape.split("x"))
         lens = [int(rng.integers(max(1, l // 2 + 1), l + 1))] + [int(rng.integers(1, l + 1)) for _ in range(b - 1)]
     return lens, [rng.integers(0, vocab_size, size=n).tolist() for n in lens]
+
+
+def cpu_merge_topk_packed(gathered, world: int, nq: int, k: int, record_bytes: int):
+    """CPU stand-in of merge_packed_kernel (crag_merge_topk_packed): `gathered` is the uint8 tensor an all-gather of
+    ResultRecords delivers -- per rank `record_bytes` bytes laid out ids int64 [nq, k] | scores fp32 [nq, k] | counts
+    int32 [nq] | padding to 8 bytes (include/crag_dense.h: crag_result_record_bytes) -- parsed where it lies."""
+    import torch
+    raw = gathered.numpy()
+    assert raw.dtype == np.uint8 and raw.size == world * record_bytes
+    g_ids = np.empty((world, nq, k), dtype=np.int64)
+    g_sc = np.empty((world, nq, k), dtype=np.float32)
+    g_ct = np.empty((world, nq), dtype=np.int32)
+    for r in range(world):
+        rec = raw[r * record_bytes:(r + 1) * record_bytes]
+        g_ids[r] = rec[:nq * k * 8].view(np.int64).reshape(nq, k)
+        g_sc[r] = rec[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k)
+        g_ct[r] = rec[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32)
+    return cpu_merge_topk(torch.from_numpy(g_ids), torch.from_numpy(g_sc), torch.from_numpy(g_ct))

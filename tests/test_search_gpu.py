@@ -682,3 +682,52 @@ def test_concurrent_host_threads_and_streams(gpu):
             assert np.array_equal(o[0].cpu().numpy(), want[i][0])
             assert np.array_equal(o[1].cpu().numpy(), want[i][1], equal_nan=True)
             assert np.array_equal(o[2].cpu().numpy(), want[i][2])
+
+
+def test_pipelined_searches_from_one_stream_equal_the_in_order_form(gpu):
+    """crag_index_search_pipelined: a run of independent searches issued from ONE stream alternates between two
+    streams of the index's own (search i + 1's preparation and scan beside search i's selection); outputs are defined
+    behind crag_index_join.  Same bits as crag_index_search_async, for mixed batch sizes and k (fp32 path, prefilter
+    path, shared selection), with the inputs produced on the caller's stream right before the call (the fork event
+    orders them) and with resident inputs (inputs_ready)."""
+    import torch
+    rng = np.random.default_rng(911)
+    n = 70_000
+    corpus = unit_rows(rng, n)
+    dev = torch.device("cuda", 0)
+    shapes = [(64, 10), (5, 50), (33, 100), (64, 10), (1, 10), (64, 128), (17, 24), (64, 10)]
+    with DenseIndex(1024, capacity=n) as ix:
+        ix.add(corpus)
+        st = torch.cuda.Stream(device=dev)
+        host_q = [rng.standard_normal((nq, 1024)).astype(np.float32) for nq, _ in shapes]
+        want = [ix.search(q, k) for q, (_, k) in zip(host_q, shapes)]
+        for ready in (False, True):
+            outs = []
+            with torch.cuda.stream(st):
+                dqs = []
+                for q in host_q:
+                    # produced ON the stream right before the search: a scaled copy (cosine is scale invariant)
+                    dq = torch.from_numpy(q).to(dev, non_blocking=False)
+                    dqs.append(dq * 3.0 if not ready else dq)
+                if ready:
+                    st.synchronize()     # resident inputs: what inputs_ready promises
+                for rep in range(3):
+                    for dq, (nq, k) in zip(dqs, shapes):
+                        o = (torch.empty(nq, k, dtype=torch.int64, device=dev), torch.empty(nq, k, dtype=torch.float32, device=dev),
+                             torch.empty(nq, dtype=torch.int32, device=dev))
+                        ix.search_pipelined(dq, k, *o, stream=st.cuda_stream, inputs_ready=ready)
+                        outs.append(o)
+                ix.join(st.cuda_stream)
+                host = [tuple(t.cpu().numpy() for t in o) for o in outs]   # (copies enqueued on `st`, behind the join)
+            for i, got in enumerate(host):
+                w = want[i % len(shapes)]
+                assert np.array_equal(got[0], w[0]) and np.array_equal(got[2], w[2])
+                if ready:
+                    assert np.array_equal(got[1], w[1], equal_nan=True)
+                else:   # the queries were scaled by 3: same order, scores equal up to the rounding of 1/||3q||
+                    assert np.nanmax(np.abs(got[1] - w[1])) <= 2e-7
+        # the in-order form still works on the same index afterwards, and a join with nothing pending is a no-op
+        ix.join(0)
+        again = ix.search(host_q[0], shapes[0][1])
+        for a, b in zip(again, want[0]):
+            assert np.array_equal(a, b, equal_nan=True)
