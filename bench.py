@@ -620,7 +620,7 @@ def compact_line(full: dict) -> dict:
                      "recall": cfg.get("recall_at_10_vs_fp64_oracle"),
                      "order_identical": cfg.get("topk_order_identical_to_oracle"),
                      "ms_per_step_median": cfg.get("ms_per_step_median")}
-    for key in ("api", "ms_per_step_in_order_api"):
+    for key in ("api",):
         if key in cfg:
             out["config"][key] = cfg[key]
     if cfg.get("per_rank_step_breakdown"):
@@ -638,9 +638,8 @@ def compact_line(full: dict) -> dict:
         out["cpu_baseline"]["encode_chunks_per_s"] = _get(base, "encode", "value")
     summ = {
         "streams2_q_per_s": _get(cfg, "steps_overlapped_on_streams", "2", "value"),
+        "pipelined_api_q_per_s": _get(full, "pipelined_api", "value"),
         "in_order_api_q_per_s": _get(full, "in_order_api", "value"),
-        "in_order_api_kernel_us": _get(full, "in_order_api", "roofline", "kernel_avg_us"),
-        "in_order_api_frac": _get(full, "in_order_api", "roofline", "frac"),
         "fp32_rows_scan_frac": _get(full, "fp32_rows_scan", "roofline", "frac"),
         "target_1m_q32_frac": _get(full, "target_1m", "q32", "roofline", "frac"),
         "target_1m_q64_frac": _get(full, "target_1m", "q64", "roofline", "frac"),
@@ -703,9 +702,10 @@ def main() -> None:
                          "weak = 100 000 rows per rank")
     ap.add_argument("--queries", type=int, default=QUERIES_PER_STEP)
     ap.add_argument("--topk", type=int, default=TOPK)
-    ap.add_argument("--api", choices=("pipelined", "async"), default="pipelined",
-                    help="N = 1: which form of the C ABI the timed steps call (pipelined: crag_index_search_pipelined + one "
-                         "crag_index_join per fence; async: crag_index_search_async, in stream order)")
+    ap.add_argument("--api", choices=("pipelined", "async"), default="async",
+                    help="N = 1: which form of the C ABI the timed steps call (async: crag_index_search_async, in stream "
+                         "order -- the default: kernel durations are undisturbed; pipelined: crag_index_search_pipelined + "
+                         "one crag_index_join per fence).  The other form is timed beside it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
@@ -797,13 +797,13 @@ def main() -> None:
     # front of every fence).  The in-order form (crag_index_search_async, one stream) is timed beside it.  N > 1: a
     # step's collective consumes the search's output on the stream -> in order.
     pipelined = world == 1 and args.api == "pipelined"
-    leg_in_order = None
-    if pipelined:
-        leg_in_order = search_leg(index, queries, k, args.steps, args.warmup, args.rounds)
     leg = search_leg(index, queries, k, args.steps, args.warmup, args.rounds, step_extra, fence_extra, outs,
                      pipelined=pipelined)
-    if leg_in_order is not None:   # same bits from both forms
-        leg["identical_to_in_order_api"] = all(bool(torch.equal(a, b)) for a, b in zip(leg["out"], leg_in_order["out"]))
+    leg_other = None
+    if world == 1:   # the other form beside it; same bits from both
+        leg_other = search_leg(index, queries, k, args.steps, min(args.warmup, 20), min(args.rounds, 3),
+                               pipelined=not pipelined, prewarm_s=0.05)
+        leg["identical_to_other_api"] = all(bool(torch.equal(a, b)) for a, b in zip(leg["out"], leg_other["out"]))
     times = leg["times"]
     per_rank = None
     if world > 1:
@@ -965,15 +965,18 @@ def main() -> None:
             # strong: the 1-GPU point of the fixed 1M-row job is config.same_job_on_one_gpu (= target_1m.q64 of the N = 1
             # line; the N = 1 `value` itself is configs[1], 100 000 rows); weak: a flat `value` is ideal
             line["config"]["scaling_curve_measured"] = "this line is one point; no curve without a multi-GPU node"
-        if leg_in_order is not None:
-            t_io = leg_in_order["times"]
-            line["config"]["ms_per_step_in_order_api"] = round(t_io[0] / args.steps * 1e3, 5)
-            line["config"]["identical_to_in_order_api"] = leg.get("identical_to_in_order_api")
-            line["config"]["outputs_identical_on_both_streams"] = leg.get("outputs_identical_on_both_streams")
-            line["in_order_api"] = {"value": round(nq * args.steps / t_io[0], 2), "unit": "queries/sec",
-                                    "ms_per_step": round(t_io[0] / args.steps * 1e3, 5),
-                                    "ms_per_step_median": round(statistics.median(t_io) / args.steps * 1e3, 5),
-                                    "roofline": roofline(rows, nq, k, leg_in_order, traffic_doc)}
+        if leg_other is not None:
+            t_o = leg_other["times"]
+            name = "in_order_api" if pipelined else "pipelined_api"
+            line["config"]["identical_to_other_api"] = leg.get("identical_to_other_api")
+            line[name] = {"api": ("crag_index_search_async" if pipelined else
+                                  "crag_index_search_pipelined + crag_index_join per fence (two streams of the index's own)"),
+                          "value": round(nq * args.steps / t_o[0], 2), "unit": "queries/sec",
+                          "ms_per_step": round(t_o[0] / args.steps * 1e3, 5),
+                          "ms_per_step_median": round(statistics.median(t_o) / args.steps * 1e3, 5),
+                          "outputs_identical_on_both_streams": (leg_other if not pipelined else leg).get(
+                              "outputs_identical_on_both_streams"),
+                          "roofline": roofline(rows, nq, k, leg_other, traffic_doc)}
         if overlap is not None:
             line["config"]["steps_overlapped_on_streams"] = overlap
         if fp32_leg is not None:

@@ -321,6 +321,7 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     ix->pass_parity ^= 1;
     if (ix->env_no_reverse) sp.reverse = 0;
     sp.unpipelined = (ix->env_unpipelined && !prefilter) ? 1 : 0;
+    sp.piece_shift = crag::crag_piece_shift(ix->corpus16 != nullptr);
 
     crag::MergeParams mp;
     mp.partial = (const uint2 *)ws->partial.p;
@@ -733,7 +734,7 @@ int crag_index_get_rows(crag_index *ix, int64_t pos, int64_t n, float *rows, int
             if (rc) return rc;
             ddst = (float *)ix->stage_rows.p;
         }
-        HIP_TRY(crag::launch_load_rows(ix->corpus, ix->dim, pos + o, m, ddst, 0));
+        HIP_TRY(crag::launch_load_rows(ix->corpus, ix->dim, pos + o, m, ddst, crag::crag_piece_shift(ix->corpus16 != nullptr), 0));
         if (!dev)
             HIP_TRY(hipMemcpy(dst, ddst, (size_t)m * ix->dim * sizeof(float), hipMemcpyDeviceToHost));
     }

@@ -35,6 +35,7 @@ struct ScanParams {
     int pub_rank;             // rank (0-based) of the key a workgroup publishes: nb * (pub_rank + 1) >= k
     int reverse;              // walk each workgroup's range back to front (alternates per search)
     int unpipelined;          // 1: use the unpipelined kernel also for k <= 32 (A/B testing, CRAG_UNPIPELINED=1)
+    int piece_shift;          // layout of the fp32 rows: crag_piece_shift(index has the fp16 mirror)
 };
 
 struct MergeParams {
@@ -143,8 +144,10 @@ hipError_t launch_merge_partials(const MergeParams &p, int nq, hipStream_t st);
 hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st);
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
                              float *inv_norm, uint32_t *irregular, _Float16 *mirror, hipStream_t st);
-hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
+hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows, int piece_shift,
                             hipStream_t st);
+// fp32 row layout (pieces of 2^shift float4 per row and tile): 5 for an index with the fp16 mirror, 2 without
+inline int crag_piece_shift(bool has_mirror) { return has_mirror ? 5 : 2; }
 hipError_t launch_count_eligible(const float *inv_norm, int64_t n, const uint32_t *mask,
                                  unsigned long long *out, hipStream_t st);
 hipError_t launch_check_ids(const int64_t *ids, int64_t n, int64_t prev, unsigned long long *out_bad,

@@ -43,10 +43,18 @@ namespace crag {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-// a row piece = 2^PIECE_SHIFT float4.  2 (64 bytes) measured against 3 and 4 on one box: 128-byte pieces make the
-// rescoring of a top-100 search 7 us cheaper (54 vs 61 us at 100 000 rows x 64 queries) but a scan instruction then
-// reads a quarter of each line it touches and the scan of the fp32 rows slows from 73 to 83 us.
-constexpr int PIECE_SHIFT = 2;
+// a row piece = 2^PS float4 (template parameter PS of everything that touches the fp32 rows).  Two layouts:
+//  * PS_SMALL = 2 (64-byte pieces) for an index WITHOUT the fp16 mirror, whose every search streams the fp32 rows: a scan
+//    instruction reads half of each line it touches and the next one the other half.  [Measured against 3 and 4 on
+//    one box: with 128-byte pieces a scan instruction reads a quarter of each line and the scan of the fp32 rows
+//    slows from 73 to 83 us at 100 000 rows x 64 queries.]
+//  * PS_BIG = 5 (512-byte pieces = a wave's whole K slice of a row) for an index WITH the mirror (the default): there
+//    the fp32 rows are read by the exact rescoring of the prefilter path -- a survivor's row is then 8 x 512 contiguous
+//    bytes in full 128-byte lines, where 64-byte pieces use half of every line they fetch: the 8 400 rows x 4 KiB of a
+//    top-100 search over 64 queries were 10-16 us of a 28 us selection launch, HBM-bound at twice the useful bytes --
+//    and by the fp32 scans of small corpora, irregular indices and the overflow fallback, which are latency-bound or
+//    rare (and ~13 % slower per byte in this layout).
+constexpr int PS_SMALL = 2, PS_BIG = 5;
 
 // ------------------------------------------------------------------------------------------
 // key helpers: a candidate is the 64-bit key (orderable(score) << 32) | ~row ; larger = better
@@ -179,6 +187,7 @@ struct ScanCtx {
 };
 
 // row range / lane geometry of one scan workgroup (everything but the query fields)
+template <int PS>
 __device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int reverse, int g, int qb) {
     ScanCtx c;
     c.lane = threadIdx.x & 63;
@@ -196,7 +205,7 @@ __device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int rever
     const int64_t t_end = (c.r_end > c.r_begin) ? ((c.r_end + 31) >> 5) : c.t_begin;
     c.n_tiles = (int)(t_end - c.t_begin);
     c.reverse = reverse != 0;
-    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * (16 << PIECE_SHIFT) + c.h * 16);
+    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * (16 << PS) + c.h * 16);
     c.qloc[0] = c.qloc[1] = 0;
     c.qok[0] = c.qok[1] = false;
     c.mrow[0] = c.mrow[1] = nullptr;
@@ -204,8 +213,9 @@ __device__ __forceinline__ ScanCtx make_row_ctx(int64_t n_rows, int G, int rever
 }
 
 // (g, qb): the workgroup's position in the scan grid -- blockIdx.x / .y of a stand-alone scan kernel
+template <int PS>
 __device__ __forceinline__ ScanCtx make_ctx(const ScanParams &p, int g, int qb) {
-    ScanCtx c = make_row_ctx(p.n_rows, p.G, p.reverse, g, qb);
+    ScanCtx c = make_row_ctx<PS>(p.n_rows, p.G, p.reverse, g, qb);
     // after the LDS reduction this wave holds accumulator registers r = 2w, 2w+1 ->
     // query (r&3) + 8*(r>>2) + 4*h of the block, corpus row j of the tile
 #pragma unroll
@@ -228,8 +238,9 @@ __device__ __forceinline__ int tile_of(const ScanCtx &c, int step) { return c.re
 
 // byte offset, relative to tile_voff(), of a lane's s-th 16-byte load of a tile (s = 0..15 inside the wave's K
 // slice): float4 kq = 2s + h of the slice sits in the 64-byte piece kq >> 2 of its row, at (kq & 3) * 16
+template <int PS>
 __device__ __forceinline__ constexpr uint32_t b_soff(int s) {
-    return (uint32_t)(((2 * s) >> PIECE_SHIFT) * (512 << PIECE_SHIFT) + ((2 * s) & ((1 << PIECE_SHIFT) - 1)) * 16);
+    return (uint32_t)(((2 * s) >> PS) * (512 << PS) + ((2 * s) & ((1 << PS) - 1)) * 16);
 }
 
 __device__ __forceinline__ uint32_t tile_voff(const ScanCtx &c, int step) {
@@ -335,10 +346,10 @@ __device__ __forceinline__ void write_lists(const ScanParams &p, const ScanCtx &
 // ---- generic kernel (any S): MFMA phase, then reduction + selection, one barrier per tile ----
 // The body is a device function so that the prefilter path's selection kernel can run it as its fallback (workgroups
 // of the same launch, see finalize_fb_kernel): slab = 64 KiB of LDS, [buf][producer wave][reg pair][lane].
-template <int S>
+template <int S, int PS>
 __device__ __forceinline__ void scan_body(const ScanParams &p, const int g, const int qb,
                                           float2 (*slab)[SCAN_WAVES][8][64]) {
-    const ScanCtx c = make_ctx(p, g, qb);
+    const ScanCtx c = make_ctx<PS>(p, g, qb);
     const int lane = c.lane, w = c.w, j = c.j;
 
     const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
@@ -349,7 +360,7 @@ __device__ __forceinline__ void scan_body(const ScanParams &p, const int g, cons
     {
         const uint32_t v0 = tile_voff(c, 0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff(s), 0, 0);
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff<PS>(s), 0, 0);
     }
     f32x4 a[16];
     float qinv[2];
@@ -389,7 +400,7 @@ __device__ __forceinline__ void scan_body(const ScanParams &p, const int g, cons
             acc = CRAG_MFMA(a[s][1], b[s][1], acc);
             acc = CRAG_MFMA(a[s][2], b[s][2], acc);
             acc = CRAG_MFMA(a[s][3], b[s][3], acc);
-            b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(s), 0, 0);
+            b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff<PS>(s), 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         // split-K reduction through LDS (double-buffered: one barrier per tile)
@@ -415,10 +426,10 @@ __device__ __forceinline__ void scan_body(const ScanParams &p, const int g, cons
     write_lists<S>(p, c, list);
 }
 
-template <int S>
+template <int S, int PS>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     __shared__ float2 slab[2][SCAN_WAVES][8][64];
-    scan_body<S>(p, blockIdx.x, blockIdx.y, slab);
+    scan_body<S, PS>(p, blockIdx.x, blockIdx.y, slab);
 }
 
 // Few candidates (the common case once the thresholds have tightened): insert them one by one into the
@@ -657,10 +668,11 @@ __device__ __forceinline__ uint32_t half_min_u32(uint32_t v) {
     return t < v ? t : v;
 }
 
+template <int PS>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     __shared__ float2 slab[2][SCAN_WAVES][8][64];
     if (p.gate && *p.gate == 0u) return;  // fallback launch behind the prefilter path: nothing overflowed
-    const ScanCtx c = make_ctx(p, blockIdx.x, blockIdx.y);
+    const ScanCtx c = make_ctx<PS>(p, blockIdx.x, blockIdx.y);
     const int lane = c.lane, w = c.w, j = c.j;
 
     const float *wg_base = p.corpus + (size_t)c.t_begin * TILE_FLOATS;
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
     {
         const uint32_t v0 = tile_voff(c, 0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff(s), 0, 0);
+        for (int s = 0; s < 16; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + b_soff<PS>(s), 0, 0);
     }
     // A operand: the raw queries in fragment order (prep_queries_kernel), lane (i = lane&31, h = lane>>5) holds
     // q[i][128w + 8s + 4h + 0..3]: one coalesced 1 KiB load per s
@@ -738,7 +750,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe_kernel(ScanParams p) {
             constexpr int m = decltype(M)::value;
             constexpr int s = m >> 2, cc = m & 3;
             acc = CRAG_MFMA(a[s][cc], b[s][cc], acc);
-            if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(s), 0, 0);
+            if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff<PS>(s), 0, 0);
             if constexpr ((m & 1) == 0 && (m >> 1) < PIPE_OPS) {
                 pipe_bg<(m >> 1)>(p, c, slab, wbuf ^ 1, prev, st);
             }
@@ -995,13 +1007,13 @@ __device__ __forceinline__ void pipe2_bg(const ScanParams &p, const ScanCtx &c, 
     }
 }
 
-template <int KS, int NQB>
+template <int KS, int NQB, int PS>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) {
     __shared__ Pipe2Lds<KS, NQB> L;
     if (p.gate && *p.gate == 0u) return;  // fallback launch behind the prefilter path: nothing overflowed
     constexpr int RING = NQB == 2 ? 8 : 16;   // B prefetch ring depth (loads in flight per wave)
     constexpr int SLOTS = 64 * NQB;           // MFMAs per tile and wave
-    const ScanCtx c = make_ctx(p, blockIdx.x, blockIdx.y);  // row range; its query fields are not used here
+    const ScanCtx c = make_ctx<PS>(p, blockIdx.x, blockIdx.y);  // row range; its query fields are not used here
     const int lane = c.lane, w = c.w, j = c.j;
     Pipe2Ctx<NQB> c2;
     c2.bucket = c.g % p.nb;
@@ -1025,7 +1037,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
     u32x4 b[RING];
     uint32_t vcur = tile_voff(c, 0);
 #pragma unroll
-    for (int s = 0; s < RING; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + b_soff(s), 0, 0);
+    for (int s = 0; s < RING; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + b_soff<PS>(s), 0, 0);
 
     // A operand: the raw queries of the block(s) in fragment order (prep_queries_kernel), lane (i = lane&31, h)
     // holds q[i][128w + 8s + 4h + 0..3]; 1/||q|| (also prepared) is applied to the score later
@@ -1118,15 +1130,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_pipe2_kernel(ScanParams p) 
                     for (int ds = 0; ds < 2; ++ds) {
                         constexpr int base = 2 * grp;
                         const int st2 = base + ds;
-                        if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + b_soff(st2 + 8), 0, 0);
-                        else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(st2 - 8), 0, 0);
+                        if constexpr (base < 8) b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vcur + b_soff<PS>(st2 + 8), 0, 0);
+                        else b[(base + ds) & 7] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff<PS>(st2 - 8), 0, 0);
                     }
                 }
             } else {
                 constexpr int s = m >> 2, cc = m & 3;
                 if constexpr (m == 0) acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], zero16);
                 else acc[0] = CRAG_MFMA(a[0][s][cc], b[s][cc], acc[0]);
-                if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(s), 0, 0);
+                if constexpr (cc == 3) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff<PS>(s), 0, 0);
             }
             if constexpr ((m & 1) == 0 && m >= OPS0) {
                 constexpr int o = (m - OPS0) >> 1;
@@ -1482,6 +1494,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 // operand -- [tile][K slice w][k-step t8][lane (h, j)][8 halves], the halves being dims 128w + 16 t8 + 8 (e >> 2) +
 // 4h + (e & 3) -- computed exactly as the scan would on the fly (fp32 multiply by 1/||row||, v_cvt_pk_f16_f32), so a
 // scan of the mirror sees bit for bit the operand a scan of the fp32 rows builds in registers.
+template <int PS>
 __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int dim, int64_t pos,
                                                          float *corpus, float *inv_norm, uint32_t *irregular,
                                                          _Float16 *mirror) {
@@ -1499,7 +1512,7 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int 
             if (4 * kq + c < dim) v[c] = src[4 * kq + c];
     }
     const int64_t row = pos + i;
-    float *dst = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> PIECE_SHIFT) * 32 + (row & 31)) * (4 << PIECE_SHIFT) + (kq & ((1 << PIECE_SHIFT) - 1)) * 4;
+    float *dst = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> PS) * 32 + (row & 31)) * (4 << PS) + (kq & ((1 << PS) - 1)) * 4;
     *reinterpret_cast<f32x4 *>(dst) = v;
     double ss = (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
     ss = block_sum_256(ss, sh);
@@ -1533,12 +1546,13 @@ __global__ __launch_bounds__(256) void store_rows_kernel(const float *rows, int 
     }
 }
 
+template <int PS>
 __global__ __launch_bounds__(256) void load_rows_kernel(const float *corpus, int dim, int64_t pos,
                                                         float *rows) {
     const int64_t i = blockIdx.x;
     const int kq = threadIdx.x;
     const int64_t row = pos + i;
-    const float *src = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> PIECE_SHIFT) * 32 + (row & 31)) * (4 << PIECE_SHIFT) + (kq & ((1 << PIECE_SHIFT) - 1)) * 4;
+    const float *src = corpus + (size_t)(row >> 5) * TILE_FLOATS + ((size_t)(kq >> PS) * 32 + (row & 31)) * (4 << PS) + (kq & ((1 << PS) - 1)) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
     float *dst = rows + (size_t)i * dim;
 #pragma unroll
@@ -1603,8 +1617,7 @@ constexpr int PF_STAGE = PF_FLUSH_ABOVE + 2048;    // per-workgroup staging entr
 constexpr int PF_PER = (PF_STAGE + SCAN_THREADS - 1) / SCAN_THREADS;   // staged entries per thread in a sift
 constexpr int PF_TAU_CELL = 128;                   // cell of a query's bound record that holds the DERIVED bound
 constexpr int PF_STASH = 4;                        // tiles scored before the first bound can have arrived
-constexpr int PF_DERIVE_LAG_DEFAULT = 2;           // tiles between a publish and the delegates' derivation
-constexpr int PF_READ_LAG_DEFAULT = 4;             // ... and every wave's read of the derived bounds (<= PF_STASH)
+// (the lags between a publish, the delegates' derivation and every wave's read -- 2 and 4 tiles -- are PfParams fields)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1849,7 +1862,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     c.j = c.lane & 31;
     c.h = c.lane >> 5;
     c.reverse = p.reverse != 0;
-    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * (16 << PIECE_SHIFT) + c.h * 16);
+    constexpr int PS = PS_SMALL;   // (the fp32 rows are scanned here only for an index WITHOUT the mirror)
+    c.lane_off = (uint32_t)(c.w * (KSLICE * 32 * 4) + c.j * (16 << PS) + c.h * 16);
     {   // whole tiles per workgroup: tiles [nt*g/G, nt*(g+1)/G) in 32-bit arithmetic (nt < 2^27, G < 2^16)
         const uint32_t nt = (uint32_t)((p.n_rows + 31) >> 5), G = (uint32_t)p.G, g = (uint32_t)c.g;
         const uint32_t qt = nt / G, rt = nt - qt * G;
@@ -1882,7 +1896,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     {
         const uint32_t v0 = voff(0);
 #pragma unroll
-        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (MIRROR ? (uint32_t)s * 1024u : b_soff(s)), 0, AUX);
+        for (int s = 0; s < NB; ++s) b[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, v0 + (MIRROR ? (uint32_t)s * 1024u : b_soff<PS>(s)), 0, AUX);
     }
     // A operand: fp16 unit queries in fragment order: lane (i, h) holds for k-step t8 the dims
     // 128w + 16 t8 + 8 (e >> 2) + 4h + (e & 3), e = 0..7 -- the order two consecutive B loads deliver
@@ -2068,8 +2082,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             if constexpr (MIRROR) {
                 b[t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + t8 * 1024, 0, AUX);
             } else {
-                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8), 0, AUX);
-                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff(2 * t8 + 1), 0, AUX);
+                b[2 * t8] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff<PS>(2 * t8), 0, AUX);
+                b[2 * t8 + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vnext + b_soff<PS>(2 * t8 + 1), 0, AUX);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -2247,14 +2261,15 @@ constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's
 // float4 are fetched first, all of them (32 independent 16-byte loads in flight, four per 64-byte piece of the
 // row: latency is everything here), then the fmaf chain runs in the scan's k order:
 // s = 0..15, then component, then lane half (k = 0, 1 of one 32x32x2 MFMA).
+template <int PS>
 __device__ __forceinline__ float exact_slice_dot(const f32x4 *qslice /* [16][2] float4 in LDS */,
                                                  const f32x4 *ctile /* tile base + slice */, int jrow) {
     f32x4 c0[16], c1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        // float4 kq = 2s (and 2s + 1) of the slice: piece kq >> PIECE_SHIFT of the row
-        c0[s] = ctile[(((2 * s) >> PIECE_SHIFT) * 32 + jrow) * (1 << PIECE_SHIFT) + ((2 * s) & ((1 << PIECE_SHIFT) - 1))];
-        c1[s] = ctile[(((2 * s) >> PIECE_SHIFT) * 32 + jrow) * (1 << PIECE_SHIFT) + ((2 * s) & ((1 << PIECE_SHIFT) - 1)) + 1];
+        // float4 kq = 2s (and 2s + 1) of the slice: piece kq >> PS of the row
+        c0[s] = ctile[(((2 * s) >> PS) * 32 + jrow) * (1 << PS) + ((2 * s) & ((1 << PS) - 1))];
+        c1[s] = ctile[(((2 * s) >> PS) * 32 + jrow) * (1 << PS) + ((2 * s) & ((1 << PS) - 1)) + 1];
     }
     float acc = 0.f;
 #pragma unroll
@@ -2301,7 +2316,7 @@ union FinFbLds {
 //  * Both roles leave the workspace clean: the selection block of query q zeroes the query's candidate count and
 //    class maxima when it is done with them (the next search's scan finds zeros); the overflow word holds the
 //    SEQUENCE NUMBER of the search that overflowed (never reset: the next search compares with its own number).
-template <int S>
+template <int S, int PS>
 __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) {
     __shared__ FinFbLds U;
     __shared__ int s_last;
@@ -2310,7 +2325,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     if ((int)blockIdx.x >= p.nq * R) {
         if (__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.seq) return;
         const int b = (int)blockIdx.x - p.nq * R;
-        scan_body<S>(p.scan, b % p.scan.G, b / p.scan.G, U.slab);
+        scan_body<S, PS>(p.scan, b % p.scan.G, b / p.scan.G, U.slab);
         // every wave drains its own list stores, then the barrier; one lane releases them and draws a ticket
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -2577,7 +2592,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
                     rid = p.ids ? p.ids[row] : (int64_t)row;
                 }
                 const f32x4 *ctile = reinterpret_cast<const f32x4 *>(p.corpus + (size_t)(row >> 5) * TILE_FLOATS) + (size_t)sub * 32 * 32;
-                part = exact_slice_dot(&qs[sub][0][0], ctile, (int)(row & 31u));
+                part = exact_slice_dot<PS>(&qs[sub][0][0], ctile, (int)(row & 31u));
             }
             // the 8 slice sums in wave order 0..7 (the scan kernels' split-K reduction order)
             float d = __shfl(part, (tid & 63 & ~7) | 0);
@@ -2760,22 +2775,30 @@ hipError_t launch_scan(const ScanParams &p, int q_blocks, hipStream_t st, const 
         name = "crag::" #__VA_ARGS__;                                 \
         hipLaunchKernelGGL((__VA_ARGS__), GRID_, block, 0, st, p);    \
     } while (0)
+    const bool big = p.piece_shift == PS_BIG;   // (the row layout of an index with the fp16 mirror)
+#define CRAG_LAUNCH_PS(GRID_, K_, ...)                                          \
+    do {                                                                        \
+        if (big) CRAG_LAUNCH(GRID_, K_<__VA_ARGS__, PS_BIG>);                    \
+        else CRAG_LAUNCH(GRID_, K_<__VA_ARGS__, PS_SMALL>);                      \
+    } while (0)
     if (p.unpipelined) {  // A/B testing only
-        if (ks == 1) CRAG_LAUNCH(grid, scan_kernel<1>);
-        else if (ks == 2) CRAG_LAUNCH(grid, scan_kernel<2>);
-        else CRAG_LAUNCH(grid, scan_kernel<4>);
+        if (ks == 1) CRAG_LAUNCH_PS(grid, scan_kernel, 1);
+        else if (ks == 2) CRAG_LAUNCH_PS(grid, scan_kernel, 2);
+        else CRAG_LAUNCH_PS(grid, scan_kernel, 4);
     } else if (p.wide) {  // 64 queries per pass (q_blocks is even): the matrix-pipe-bound kernel
         const dim3 g2(p.G, q_blocks / 2);
-        if (ks == 1) CRAG_LAUNCH(g2, scan_pipe2_kernel<1, 2>);
-        else if (ks == 2) CRAG_LAUNCH(g2, scan_pipe2_kernel<2, 2>);
-        else CRAG_LAUNCH(g2, scan_pipe2_kernel<4, 2>);
+        if (ks == 1) CRAG_LAUNCH_PS(g2, scan_pipe2_kernel, 1, 2);
+        else if (ks == 2) CRAG_LAUNCH_PS(g2, scan_pipe2_kernel, 2, 2);
+        else CRAG_LAUNCH_PS(g2, scan_pipe2_kernel, 4, 2);
     } else if (ks == 1) {
-        CRAG_LAUNCH(grid, scan_pipe_kernel);
+        if (big) CRAG_LAUNCH(grid, scan_pipe_kernel<PS_BIG>);
+        else CRAG_LAUNCH(grid, scan_pipe_kernel<PS_SMALL>);
     } else if (ks == 2) {
-        CRAG_LAUNCH(grid, scan_pipe2_kernel<2, 1>);
+        CRAG_LAUNCH_PS(grid, scan_pipe2_kernel, 2, 1);
     } else {
-        CRAG_LAUNCH(grid, scan_pipe2_kernel<4, 1>);
+        CRAG_LAUNCH_PS(grid, scan_pipe2_kernel, 4, 1);
     }
+#undef CRAG_LAUNCH_PS
 #undef CRAG_LAUNCH
     if (kernel_name) *kernel_name = name;
     return hipGetLastError();
@@ -2819,9 +2842,15 @@ hipError_t launch_prefilter(const PfParams &p, int nqb, int passes, hipStream_t 
 hipError_t launch_finalize(const FinParams &p, hipStream_t st) {
     const dim3 grid(p.nq * p.rsplit + p.fb_blocks), block(SCAN_THREADS);
     const int ks = (p.k + 31) / 32;  // list slots of the fallback scan
-    if (ks == 1) hipLaunchKernelGGL(finalize_fb_kernel<1>, grid, block, 0, st, p);
-    else if (ks == 2) hipLaunchKernelGGL(finalize_fb_kernel<2>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(finalize_fb_kernel<4>, grid, block, 0, st, p);
+    if (p.scan.piece_shift == PS_BIG) {
+        if (ks == 1) hipLaunchKernelGGL((finalize_fb_kernel<1, PS_BIG>), grid, block, 0, st, p);
+        else if (ks == 2) hipLaunchKernelGGL((finalize_fb_kernel<2, PS_BIG>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((finalize_fb_kernel<4, PS_BIG>), grid, block, 0, st, p);
+    } else {
+        if (ks == 1) hipLaunchKernelGGL((finalize_fb_kernel<1, PS_SMALL>), grid, block, 0, st, p);
+        else if (ks == 2) hipLaunchKernelGGL((finalize_fb_kernel<2, PS_SMALL>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((finalize_fb_kernel<4, PS_SMALL>), grid, block, 0, st, p);
+    }
     return hipGetLastError();
 }
 
@@ -2838,15 +2867,19 @@ hipError_t launch_merge_results(const XMergeParams &p, hipStream_t st) {
 hipError_t launch_store_rows(const float *rows, int dim, int64_t pos, int64_t n, float *corpus,
                              float *inv_norm, uint32_t *irregular, _Float16 *mirror, hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, rows, dim, pos, corpus,
+    // the row layout follows the mirror: PS_BIG with it, PS_SMALL without (see PS_SMALL / PS_BIG)
+    if (mirror) hipLaunchKernelGGL(store_rows_kernel<PS_BIG>, dim3((unsigned)n), dim3(256), 0, st, rows, dim, pos, corpus,
+                                   inv_norm, irregular, mirror);
+    else hipLaunchKernelGGL(store_rows_kernel<PS_SMALL>, dim3((unsigned)n), dim3(256), 0, st, rows, dim, pos, corpus,
                        inv_norm, irregular, mirror);
     return hipGetLastError();
 }
 
-hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows,
+hipError_t launch_load_rows(const float *corpus, int dim, int64_t pos, int64_t n, float *rows, int piece_shift,
                             hipStream_t st) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(load_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, corpus, dim, pos, rows);
+    if (piece_shift == PS_BIG) hipLaunchKernelGGL(load_rows_kernel<PS_BIG>, dim3((unsigned)n), dim3(256), 0, st, corpus, dim, pos, rows);
+    else hipLaunchKernelGGL(load_rows_kernel<PS_SMALL>, dim3((unsigned)n), dim3(256), 0, st, corpus, dim, pos, rows);
     return hipGetLastError();
 }
 
