@@ -8,6 +8,7 @@
 // post-processing; the model family's public architecture for the layer (checked against
 // transformers' Qwen3Model in tests/test_encoder_gpu.py).
 
+#include "crag_arch.h"
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <type_traits>

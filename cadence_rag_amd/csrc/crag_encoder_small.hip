@@ -35,6 +35,7 @@
 // then * w rounded to bf16; cos/sin cast to bf16; P rounded to bf16 after an fp32 softmax) -- tests compare the
 // fused path with the unfused kernels and with transformers' Qwen3Model.
 
+#include "crag_arch.h"
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdint.h>

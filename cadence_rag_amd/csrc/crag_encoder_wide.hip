@@ -1,0 +1,251 @@
+// crag_encoder_wide.hip — the linear layers of the Qwen3-Embedding decoder at 64 / 128 token rows: what the gateway's
+// dynamic batcher hands the model (/root/reference/P620_TRITON_QWEN3_4B_EMBEDDING_RUNBOOK.md:304,331-334:
+// max_batch_size 8, preferred_batch_size [1, 2, 4, 8] -- 3 to 8 short queries, or one query of 33 to 128 tokens).
+// C ABI: include/crag_encoder.h (crag_enc_wide_gemm, crag_enc_wide_reduce).
+//
+// At this size a layer is still a WEIGHT STREAM (202 MB of bf16 weights against <= 128 rows of activations: 25 us at
+// 8 TB/s, 16 GFLOP = 6 us of MFMA time), but the activations no longer fit a wave's registers (crag_encoder_small.hip
+// keeps a wave's K slice of 16 / 32 rows there), and the library's small-M GEMM tiles stream the weights at 1.3 TB/s.
+//
+//   * A workgroup = 4 waves = 128 rows of the weight (each wave its own 32 rows: the A operand of
+//     v_mfma_f32_32x32x16_bf16, streamed once from HBM straight into registers, 8 fragments = 8 KiB in flight per
+//     wave, stored in that order by wide_weight()); the waves share the B operand: a 128-column chunk of the
+//     activations, staged through LDS in B-fragment order (full 256-byte rows from L2, conflict-free ds_read_b128),
+//     double-buffered, one barrier per chunk.  Per 16-element k-step a wave loads 1 KiB of weights and reads MG KiB of
+//     LDS for MG MFMAs (MG = rows / 32): bytes of activations per byte of weight = MG, the same for every projection.
+//   * N / 128 is 20 (o, down) to 152 (gate|up) tiles: to occupy the chip the K range is SPLIT over `splitk` workgroups
+//     per tile.  Each writes its fp32 partial tile in register order (one contiguous KiB per wave-instruction);
+//     crag_enc_wide_reduce sums the splits in a fixed order, rounds to bf16 once (the rounding point of the unsplit
+//     GEMM) and applies the SwiGLU epilogue where asked.  [An in-launch "last arriver reduces" is ruled out by the
+//     slab size: splitk x 64 KiB per tile for ONE workgroup to read is 5-30 us of serial tail; a separate pass over the
+//     whole output uses every CU for ~10 MB.]
+//
+// Arithmetic: bf16 operands, fp32 accumulation (MFMA), the K splits added in split order in fp32, one rounding to
+// bf16; SwiGLU with crag_enc_swiglu's roundings (bf16 gate -> silu in fp32 -> bf16 -> x bf16 up -> bf16).
+
+#include "crag_arch.h"
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/crag_encoder.h"
+
+extern "C" void crag_set_error_(const char *msg);  // crag_api.hip
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint16_t u16;
+
+int wfail(const char *fmt, ...) {
+    char buf[384];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    crag_set_error_(buf);
+    return -1;
+}
+
+int whip_ok(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s launch failed: %s", what, hipGetErrorString(e));
+        crag_set_error_(buf);
+        return -2;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+
+constexpr int WIDE_BK = 128;            // activation columns per LDS chunk
+constexpr int WIDE_KS = WIDE_BK / 16;   // k-steps (MFMAs per token group) per chunk = the weight ring's depth
+constexpr int WIDE_THREADS = 256;
+
+struct WideParams {
+    const u16 *x;      // [32 MG, K] bf16 activations (rows beyond the real ones are padding: finite, results dropped)
+    const u16 *ww;     // weights, [N / 32][K / 16][64 lanes][8]: lane l = row (l & 31), k = 8 (l >> 5) + e
+    float *partial;    // [splitk][N / 32][MG][4][64][4] fp32: the accumulator registers as they are
+    int K, n32, splitk;
+};
+
+template <int MG>
+__global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
+    __shared__ bf16x8 xs[2][WIDE_KS][MG][64];   // B fragments of a chunk: lane l = token (l & 31), k = 8 (l >> 5) + e
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = (int)blockIdx.x * 4 + w;           // this wave's 32 weight rows
+    const int split = blockIdx.y;
+    const int chunks = p.K / WIDE_BK;
+    const int c0 = (int)((long long)chunks * split / p.splitk), c1 = (int)((long long)chunks * (split + 1) / p.splitk);
+    const bool rows_ok = n32 < p.n32;                  // (N is a multiple of 128 for every projection; kept for safety)
+
+    // activation staging: piece q of 16 bytes = x[token][128 c + 8 (q & 15) .. + 7], token = q >> 4; a row of a chunk is
+    // 256 contiguous bytes = 16 consecutive threads.  It lands at fragment (k-step (q & 15) >> 1, group token >> 5),
+    // lane 32 ((q & 15) & 1) + (token & 31).
+    constexpr int PIECES = MG * 32 * 16 / WIDE_THREADS;   // per thread: 4 (64 rows) or 8 (128 rows)
+    const u16 *xsrc[PIECES];
+    bf16x8 *xdst[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int q = tid + WIDE_THREADS * i, token = q >> 4, piece = q & 15;
+        xsrc[i] = p.x + (size_t)token * p.K + piece * 8;
+        xdst[i] = &xs[0][piece >> 1][token >> 5][32 * (piece & 1) + (token & 31)];
+    }
+    constexpr int BUF_STRIDE = WIDE_KS * MG * 64;          // bf16x8 elements between the two LDS buffers
+    const bf16x8 *wsrc = reinterpret_cast<const bf16x8 *>(p.ww) + ((size_t)(rows_ok ? n32 : 0) * (p.K / 16)) * 64 + lane;
+
+    f32x16 acc[MG];
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mg][r] = 0.f;
+    if (c0 < c1) {
+        bf16x8 wr[WIDE_KS];
+#pragma unroll
+        for (int s = 0; s < WIDE_KS; ++s) wr[s] = __builtin_nontemporal_load(wsrc + (size_t)(c0 * WIDE_KS + s) * 64);
+        bf16x8 xr[PIECES];
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) xr[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)c0 * WIDE_BK);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) xdst[i][0] = xr[i];
+        __syncthreads();
+        int buf = 0;
+        for (int c = c0; c < c1; ++c) {
+            const bool more = c + 1 < c1;   // uniform
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) xr[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)(c + 1) * WIDE_BK);
+            }
+#pragma unroll
+            for (int s = 0; s < WIDE_KS; ++s) {
+                const bf16x8 wv = wr[s];
+                if (more) wr[s] = __builtin_nontemporal_load(wsrc + (size_t)((c + 1) * WIDE_KS + s) * 64);
+#pragma unroll
+                for (int mg = 0; mg < MG; ++mg)
+                    acc[mg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xs[buf][s][mg][lane], acc[mg], 0, 0, 0);
+            }
+            if (more) {   // the other buffer was last read before the previous barrier
+#pragma unroll
+                for (int i = 0; i < PIECES; ++i) xdst[i][(buf ^ 1) * BUF_STRIDE] = xr[i];
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    if (!rows_ok) return;
+    // D[row 8 b + 4 h + c][token j] = acc[4 b + c] of lane (h, j): stored as they are, 16 bytes per lane and b
+    f32x4_t *out = reinterpret_cast<f32x4_t *>(p.partial) + (((size_t)split * p.n32 + n32) * MG) * 4 * 64 + lane;
+#pragma unroll
+    for (int mg = 0; mg < MG; ++mg)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            out[(mg * 4 + b) * 64] = f32x4_t{acc[mg][4 * b], acc[mg][4 * b + 1], acc[mg][4 * b + 2], acc[mg][4 * b + 3]};
+}
+
+struct WideReduceParams {
+    const float *partial;
+    u16 *out;          // [m_rows, ld_out]
+    int n32, splitk, mg_count, m_rows, ld_out, epilogue;
+};
+
+// One wave per (32 weight rows, token group): sums the splits in split order, rounds once, writes bf16.
+// epilogue 1: the 32 rows are 16 gate rows then the 16 up rows of the same features (wide_gate_up_weight):
+// out[token][16 tile + f] = silu(gate_f) * up_f.
+__global__ __launch_bounds__(WIDE_THREADS) void wide_reduce_kernel(WideReduceParams p) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = (int)blockIdx.x * 4 + wv;            // (n32, mg)
+    if (item >= p.n32 * p.mg_count) return;
+    const int n32 = item / p.mg_count, mg = item % p.mg_count;
+    const int h = lane >> 5, token = 32 * mg + (lane & 31);
+    f32x4_t sum[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sum[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const size_t split_stride = (size_t)p.n32 * p.mg_count * 4 * 64;
+    const f32x4_t *src = reinterpret_cast<const f32x4_t *>(p.partial) + ((size_t)n32 * p.mg_count + mg) * 4 * 64 + lane;
+    for (int s = 0; s < p.splitk; ++s) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sum[b] += src[(size_t)s * split_stride + b * 64];
+    }
+    if (token >= p.m_rows) return;
+    if (p.epilogue == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {   // rows 8 b + 4 h + 0..3
+            uint2 o;
+            o.x = (uint32_t)f2bf(sum[b][0]) | ((uint32_t)f2bf(sum[b][1]) << 16);
+            o.y = (uint32_t)f2bf(sum[b][2]) | ((uint32_t)f2bf(sum[b][3]) << 16);
+            *reinterpret_cast<uint2 *>(p.out + (size_t)token * p.ld_out + 32 * n32 + 8 * b + 4 * h) = o;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {   // gate rows 8 b + 4 h + c, up rows 16 + the same
+            u16 o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gt = bf2f(f2bf(sum[b][c]));
+                const float act = bf2f(f2bf(gt / (1.f + __expf(-gt))));
+                o[c] = f2bf(act * bf2f(f2bf(sum[b + 2][c])));
+            }
+            *reinterpret_cast<uint2 *>(p.out + (size_t)token * p.ld_out + 16 * n32 + 8 * b + 4 * h) =
+                make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t crag_enc_wide_partial_bytes(int m_pad, int n, int splitk) {
+    if (m_pad <= 0 || n <= 0 || splitk <= 0) return -1;
+    return (int64_t)splitk * n * m_pad * 4;
+}
+
+int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, int m_pad, int n, int k, int splitk,
+                       void *stream) {
+    if (!x || !ww || !partial) return wfail("wide_gemm: NULL pointer");
+    if (m_pad != 64 && m_pad != 128) return wfail("wide_gemm: m_pad must be 64 or 128 (got %d)", m_pad);
+    if (n <= 0 || n % 128) return wfail("wide_gemm: n must be a multiple of 128 (got %d)", n);
+    if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm: k must be a multiple of %d (got %d)", WIDE_BK, k);
+    if (splitk <= 0 || splitk > k / WIDE_BK) return wfail("wide_gemm: splitk must be in [1, k / %d] (got %d)", WIDE_BK, splitk);
+    WideParams p;
+    p.x = x;
+    p.ww = ww;
+    p.partial = partial;
+    p.K = k;
+    p.n32 = n / 32;
+    p.splitk = splitk;
+    const dim3 grid((unsigned)(n / 128), (unsigned)splitk);
+    if (m_pad == 64) hipLaunchKernelGGL(wide_gemm_kernel<2>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wide_gemm_kernel<4>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    return whip_ok("wide_gemm");
+}
+
+int crag_enc_wide_reduce(const float *partial, uint16_t *out, int m_rows, int m_pad, int n, int splitk, int epilogue,
+                         void *stream) {
+    if (!partial || !out) return wfail("wide_reduce: NULL pointer");
+    if (m_pad != 64 && m_pad != 128) return wfail("wide_reduce: m_pad must be 64 or 128 (got %d)", m_pad);
+    if (m_rows <= 0 || m_rows > m_pad) return wfail("wide_reduce: 0 < m_rows <= m_pad");
+    if (n <= 0 || n % 128 || splitk <= 0) return wfail("wide_reduce: bad sizes n=%d splitk=%d", n, splitk);
+    if (epilogue != 0 && epilogue != 1) return wfail("wide_reduce: epilogue must be 0 or 1");
+    WideReduceParams p;
+    p.partial = partial;
+    p.out = out;
+    p.n32 = n / 32;
+    p.splitk = splitk;
+    p.mg_count = m_pad / 32;
+    p.m_rows = m_rows;
+    p.ld_out = epilogue ? n / 2 : n;
+    p.epilogue = epilogue;
+    const int items = p.n32 * p.mg_count;
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)((items + 3) / 4)), dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    return whip_ok("wide_reduce");
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 // score += 1/(k + rank) over the lanes in lane order (fp64, same summation order => bit-identical to
 // the Python floats), the first row seen for a key is kept, result sorted by score descending with
 // a STABLE sort, i.e. ties keep first-insertion order.
+#include "crag_arch.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,10 +85,18 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
             lane_of[i] = (uint8_t)l;
             // find or claim the key's slot; remember the slot in first[] for now
             uint32_t sl = fuse_hash(k) & (FUSE_SLOTS - 1);
-            for (;;) {
-                const unsigned long long prev = atomicCAS(&slot_key[sl], EMPTY, (unsigned long long)k);
-                if (prev == EMPTY || prev == (unsigned long long)k) break;
+            bool placed = false;
+            for (int tries = 0; tries < FUSE_SLOTS; ++tries) {   // (bounded: a full table must not spin -- the host keeps
+                const unsigned long long prev = atomicCAS(&slot_key[sl], EMPTY, (unsigned long long)k);   // total <= SLOTS / 2)
+                if (prev == EMPTY || prev == (unsigned long long)k) {
+                    placed = true;
+                    break;
+                }
                 sl = (sl + 1) & (FUSE_SLOTS - 1);
+            }
+            if (!placed) {   // cannot happen with total <= FUSE_MAX_ITEMS; if it ever does: the quadratic path answers
+                s_dup = 1;
+                continue;
             }
             first[i] = (int)sl;
             atomicMin(&slot_first[sl], i);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "crag_arch.h"
+
 namespace crag {
 
 constexpr int TILE_ROWS = 32;                 // corpus rows per tile (= MFMA N)

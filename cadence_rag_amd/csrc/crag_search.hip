@@ -2253,7 +2253,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
 // exactly by ranking the last bucket: three more barriers for one or two rows fewer to rescore.]
 constexpr int FIN_SKIP_BITS = 12;
 constexpr int FIN_THREADS = SCAN_THREADS;   // all eight waves of a selection block work (round 3: four of them)
-constexpr int FIN_WAVE_PER = 16;            // candidates per lane in the one-wave search for the k-th approximate score
 constexpr int FIN_ROUND = 4096;             // candidates examined per round (all of them, for k <= 128 on the bench's corpora)
 constexpr int FIN_BEST = FIN_ROUND + 128;   // exact keys kept in LDS (a round's survivors + the running top-k)
 
@@ -2428,73 +2427,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
                 if (rank == k - 1) s_kth = mine & ~((1u << FIN_SKIP_BITS) - 1u);   // (the same value the searches below end with)
             }
             __syncthreads();
-        } else if (C < 64 * FIN_WAVE_PER) {   // (at most 1023: the packed 11-bit / 10-bit count fields below cannot wrap)
-            // Up to 1024 candidates (what a top-50 / top-100 search leaves since the scan sifts its staging buffer): ONE
-            // wave holds them all, 16 per lane, and runs the whole bit search (see below) without a barrier or an LDS
-            // word: per round seven ballots per register, scalar counts.  [Eight waves + a barrier per round: 0.9-1.3 us
-            // a round, 6.6 us for the five rounds of a typical top-100 search.]
-            if (wave == 0) {
-                uint32_t v[FIN_WAVE_PER];
-                uint32_t vmax = 0u, vmin = 0xffffffffu;
-#pragma unroll
-                for (int i = 0; i < FIN_WAVE_PER; ++i) {
-                    const int e = tid + i * 64;
-                    v[i] = e < C ? lcand[e].x : 0u;
-                    if (e < C) {
-                        vmax = v[i] > vmax ? v[i] : vmax;
-                        vmin = v[i] < vmin ? v[i] : vmin;
-                    }
-                }
-                const int ln = tid & 63;
-                vmax = wave_reduce_u32(vmax, ln, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
-                vmin = wave_reduce_u32(vmin, ln, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
-                const uint32_t diff = vmax ^ vmin;
-                const int top0 = diff ? 32 - __builtin_clz(diff) : 0;
-                const int top = top0 > FIN_SKIP_BITS ? top0 : FIN_SKIP_BITS;
-                uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
-                // One bit per round: count the candidates >= ans | bit per LANE (a compare and an add-with-carry per
-                // register), one wave sum on the VALU (DPP + v_permlane swaps), keep the bit if k candidates reach it.
-                // [With one wave on its SIMD every instruction costs its full latency: three bits per round -- seven
-                // thresholds, three packed counters, three wave sums -- were ~230 instructions a round, 4.4 us for the
-                // five rounds of a typical top-100 search whatever the reduction was made of (ballot + s_bcnt1,
-                // ds_bpermute shuffles, DPP); one bit per round is ~36.]
-                for (int bit = top - 1; bit >= FIN_SKIP_BITS; --bit) {
-                    const uint32_t t = ans | (1u << bit);
-                    uint32_t c = 0u;
-#pragma unroll
-                    for (int i = 0; i < FIN_WAVE_PER; ++i)
-                        if (i * 64 < C) c += v[i] >= t ? 1u : 0u;   // (uniform branch; absent slots hold 0 < t)
-                    c = wave_reduce_u32(c, ln, [](uint32_t x, uint32_t y) { return x + y; });
-                    if ((int)c >= k) ans = t;
-                }
-                if (tid == 0) s_kth = ans;
-            }
-            __syncthreads();
         } else {
-            // Search on the orderable score for the largest T with at least k candidates >= T, three bits per round:
-            // a wave counts its candidates (<= 8 per thread, in registers; beyond FIN_ROUND candidates it re-reads them)
-            // above each of the seven thresholds of the round with ballots -- the counts are scalars --, lane 0 posts
-            // them packed in two 64-bit words, one barrier, everybody adds the eight waves' words.  The candidates sit
-            // just above a common threshold, so their high bits agree: the search starts below the highest bit in which
-            // any two of them differ.
-            // [A radix select with an LDS histogram serialises here: a thousand atomics on ONE bin per pass.  One bit
-            // per round was twenty barriers.  Round 3 tallied digits per thread and reduced the packed counters with
-            // 24 64-bit shuffles per round: ~1.5 us a round; ranking 500 candidates by counting: 12 us.]
-            constexpr int PER = FIN_ROUND / NT;
-            uint32_t v[PER];
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                const int e = tid + i * NT;
-                v[i] = (in_lds && e < C) ? lcand[e].x : 0u;
-            }
+            // Radix-16 select on the orderable score with the digits on the LANES: lane L tests digit L & 15 against one of
+            // 32 subsets of the list (4 per wave), i.e. counts its candidates >= ans | (digit << lo) -- a read, a compare
+            // and an add per candidate, no dependent cross-lane step --; two v_permlane swaps add a wave's four subsets, the
+            // eight waves' counts meet in LDS behind one barrier, and the largest digit still reached by k candidates is a
+            // ballot away.  The candidates sit just above a common threshold, so their high bits agree: the search starts
+            // below the highest bit in which any two of them differ and ends FIN_SKIP_BITS above the bottom: four rounds for
+            // a typical top-100 search (14 bits).  [Radix 64 -- 63 thresholds per candidate -- is VALU-bound: 3-6.5 us.]
+            // [What this replaced, each measured at ~350 candidates: three bits per round with per-thread digit tallies
+            // and 24 64-bit shuffles per round 9-10 us; ranking by counting 12 us; one wave with ballots + s_bcnt1, with
+            // shuffles or with DPP wave sums, one or three bits per round: 4.4-5 us every time -- with ONE wave on its
+            // SIMD every dependent step costs its full latency, and a bit search is nothing but dependent steps.  A radix
+            // select with an LDS histogram serialises: a thousand atomics on one bin per pass.]
+            const int ln = tid & 63;
             uint32_t vmax = 0u, vmin = 0xffffffffu;
             if (in_lds) {
-#pragma unroll
-                for (int i = 0; i < PER; ++i)
-                    if (tid + i * NT < C) {
-                        vmax = v[i] > vmax ? v[i] : vmax;
-                        vmin = v[i] < vmin ? v[i] : vmin;
-                    }
+                for (int e = tid; e < C; e += NT) {
+                    const uint32_t o = lcand[e].x;
+                    vmax = o > vmax ? o : vmax;
+                    vmin = o < vmin ? o : vmin;
+                }
             } else {
                 for (int e = tid; e < C; e += NT) {
                     const uint32_t o = gcand[e].x;
@@ -2502,18 +2455,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
                     vmin = o < vmin ? o : vmin;
                 }
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint32_t a = (uint32_t)__shfl_xor((int)vmax, o), b = (uint32_t)__shfl_xor((int)vmin, o);
-                vmax = a > vmax ? a : vmax;
-                vmin = b < vmin ? b : vmin;
-            }
-            if ((tid & 63) == 0) {
-                hist[32 + (tid >> 6)] = vmax;
-                hist[40 + (tid >> 6)] = vmin;
+            vmax = wave_reduce_u32(vmax, ln, [](uint32_t x, uint32_t y) { return x > y ? x : y; });
+            vmin = wave_reduce_u32(vmin, ln, [](uint32_t x, uint32_t y) { return x < y ? x : y; });
+            uint32_t *const cnts = reinterpret_cast<uint32_t *>(hist);   // [2][8 waves][64 lanes] -- surv is free until step 2
+            uint32_t *const xch = surv;
+            (void)cnts;
+            if (ln == 0) {
+                xch[wave] = vmax;
+                xch[8 + wave] = vmin;
             }
             __syncthreads();
+#pragma unroll
             for (int i = 0; i < NT / 64; ++i) {
-                const uint32_t a = (uint32_t)hist[32 + i], b = (uint32_t)hist[40 + i];
+                const uint32_t a = xch[i], b = xch[8 + i];
                 vmax = a > vmax ? a : vmax;
                 vmin = b < vmin ? b : vmin;
             }
@@ -2522,41 +2476,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
             const int top = top0 > FIN_SKIP_BITS ? top0 : FIN_SKIP_BITS;
             uint32_t ans = top >= 32 ? 0u : (vmax >> top) << top;
             int round = 0;
-            for (int bit = top; bit > FIN_SKIP_BITS; ++round) {  // decides bits [FIN_SKIP_BITS, top) of ans, three per round
-                const int nb = bit - FIN_SKIP_BITS >= 3 ? 3 : bit - FIN_SKIP_BITS, lo = bit - nb;  // this round: bits [lo, bit)
-                // cnt[jj-1] = candidates of this wave >= ans + (jj << lo), jj = 1 .. 7 (absent slots hold 0 < ans)
-                uint32_t cnt[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
-                auto tally = [&](uint32_t x) {
-#pragma unroll
-                    for (int jj = 1; jj <= 7; ++jj)
-                        cnt[jj - 1] += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(x >= ans + ((uint32_t)jj << lo)));
-                };
+            const int digit_of = ln & 15, subset = (ln >> 4) + 4 * wave;   // 16 digits x 32 candidate subsets
+            for (int bit = top; bit > FIN_SKIP_BITS; ++round) {
+                const int nb = bit - FIN_SKIP_BITS >= 4 ? 4 : bit - FIN_SKIP_BITS, lo = bit - nb;   // this round: bits [lo, bit)
+                const uint32_t t = ans | ((uint32_t)digit_of << lo);   // (digit 0 and digits >= 2^nb are not looked at)
+                uint32_t c = 0u;
                 if (in_lds) {
-#pragma unroll
-                    for (int i = 0; i < PER; ++i) tally(v[i]);
+                    int e = subset;
+                    for (; e + 3 * 32 < C; e += 4 * 32) {   // (four reads in flight)
+                        const uint32_t x0 = lcand[e].x, x1 = lcand[e + 32].x, x2 = lcand[e + 64].x, x3 = lcand[e + 96].x;
+                        c += (x0 >= t ? 1u : 0u) + (x1 >= t ? 1u : 0u) + (x2 >= t ? 1u : 0u) + (x3 >= t ? 1u : 0u);
+                    }
+                    for (; e < C; e += 32) c += lcand[e].x >= t ? 1u : 0u;
                 } else {
-                    for (int e0 = 0; e0 < C; e0 += NT) tally(e0 + tid < C ? gcand[e0 + tid].x : 0u);   // (uniform trip count)
+                    for (int e = subset; e < C; e += 32) c += gcand[e].x >= t ? 1u : 0u;
                 }
-                unsigned long long *slot = hist + (round & 1) * 16;
-                if ((tid & 63) == 0) {
-                    slot[(tid >> 6) * 2] = (unsigned long long)cnt[0] | ((unsigned long long)cnt[1] << 16) |
-                                           ((unsigned long long)cnt[2] << 32) | ((unsigned long long)cnt[3] << 48);
-                    slot[(tid >> 6) * 2 + 1] = (unsigned long long)cnt[4] | ((unsigned long long)cnt[5] << 16) |
-                                               ((unsigned long long)cnt[6] << 32);
+                {   // the wave's four subsets of a digit: rows 0..3 of 16 lanes
+                    const auto r16 = __builtin_amdgcn_permlane16_swap(c, c, false, false);
+                    c = r16[0] + r16[1];
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+                    c = r32[0] + r32[1];
                 }
+                uint32_t *const slot = xch + 16 + (round & 1) * 128;   // [wave][digit]
+                if (ln < 16) slot[wave * 16 + ln] = c;
                 __syncthreads();
-                unsigned long long a = 0ull, b = 0ull;   // (a wave's count <= 4096 and the total <= cap < 65536: 16 bits each)
+                uint32_t total = 0u;
 #pragma unroll
-                for (int wv = 0; wv < NT / 64; ++wv) {
-                    a += slot[2 * wv];
-                    b += slot[2 * wv + 1];
-                }
-                uint32_t pick = 0u;
-                for (int jj = 7; jj >= 1; --jj) {   // the counts fall with jj: the largest digit still reached by k candidates
-                    const int at_least = (int)(((jj >= 5 ? b >> (16 * (jj - 5)) : a >> (16 * (jj - 1)))) & 0xffffull);
-                    if (pick == 0u && at_least >= k && jj < (1 << nb)) pick = (uint32_t)jj;
-                }
-                ans |= pick << lo;
+                for (int wv = 0; wv < NT / 64; ++wv) total += slot[wv * 16 + digit_of];
+                const unsigned long long reach =
+                    __builtin_amdgcn_ballot_w64((int)total >= k && ln >= 1 && ln < (1 << nb) && ln < 16);
+                const uint32_t digit = reach ? 63u - (uint32_t)__builtin_clzll(reach) : 0u;   // (the counts fall with the digit)
+                ans |= digit << lo;
                 bit = lo;
             }
             // ans = the k-th value with its low FIN_SKIP_BITS bits cleared (a lower bound on it)

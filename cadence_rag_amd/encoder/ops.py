@@ -151,3 +151,48 @@ def small_attention(qkv, q_w, k_w, cos_sin, positions, out, hq: int, hkv: int, e
                                                           positions.numel(), hq, hkv, float(eps), float(scale),
                                                           _stream()), "crag_enc_small_attention")
     return out
+
+
+# -- the linear layers at 64 / 128 token rows (csrc/crag_encoder_wide.hip) ------------------------------------------
+def wide_weight(weight: torch.Tensor) -> torch.Tensor:
+    """[n, k] bf16 (torch Linear layout) -> the A-fragment order of v_mfma_f32_32x32x16_bf16 that crag_enc_wide_gemm
+    streams: [n/32][k/16][lane = 32 (kk/8) + row][8]; n % 128 == 0, k % 128 == 0."""
+    n, k = weight.shape
+    if n % 128 or k % 128:
+        raise ValueError(f"weight [{n}, {k}] does not split into 128-row tiles of 128-element chunks")
+    return weight.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def wide_gate_up_weight(gate_up: torch.Tensor) -> torch.Tensor:
+    """The fused [2I, k] gate|up weight with every 32 rows = 16 gate rows then the 16 up rows of the same features, in
+    fragment order: the operand of wide_gemm(..., swiglu=True)."""
+    two_i, k = gate_up.shape
+    inter = two_i // 2
+    g = gate_up[:inter].view(inter // 16, 16, k)
+    u = gate_up[inter:].view(inter // 16, 16, k)
+    return wide_weight(torch.cat([g, u], dim=1).reshape(two_i, k))
+
+
+_wide_scratch: dict = {}
+
+
+def wide_gemm(x: torch.Tensor, ww: torch.Tensor, out: torch.Tensor, m_rows: int, n: int, splitk: int,
+              swiglu: bool = False, scratch: "torch.Tensor | None" = None):
+    """out[m_rows, n (or n/2)] = x[m_pad, k] @ W^T for m_pad = 64 or 128 token rows: crag_enc_wide_gemm (split-K partial
+    tiles, fp32) + crag_enc_wide_reduce (sum of the splits, one rounding to bf16, optional SwiGLU).  scratch: fp32
+    buffer of >= splitk * n * m_pad elements (one per device is kept otherwise: calls on one stream reuse it in order)."""
+    _req(x, torch.bfloat16, "x"); _req(ww, torch.bfloat16, "ww"); _req(out, torch.bfloat16, "out")
+    m_pad, k = x.shape
+    need = int(splitk) * int(n) * int(m_pad)
+    if scratch is None:
+        scratch = _wide_scratch.get(x.device)
+        if scratch is None or scratch.numel() < need:
+            scratch = _wide_scratch[x.device] = torch.empty(max(need, 4 * 19456 * 128), dtype=torch.float32, device=x.device)
+    elif scratch.dtype != torch.float32 or scratch.numel() < need:
+        raise ValueError("scratch must be a float32 tensor of at least splitk * n * m_pad elements")
+    lib = _native.load()
+    _native.check(lib.crag_enc_wide_gemm(_p(x), _p(ww), _p(scratch), int(m_pad), int(n), int(k), int(splitk), _stream()),
+                  "crag_enc_wide_gemm")
+    _native.check(lib.crag_enc_wide_reduce(_p(scratch), _p(out), int(m_rows), int(m_pad), int(n), int(splitk),
+                                           1 if swiglu else 0, _stream()), "crag_enc_wide_reduce")
+    return out

@@ -230,23 +230,43 @@ class Qwen3Encoder:
         that the tiles of a projection cover the 256 CUs evenly); CRAG_ENC_SMALL_V1=1 keeps round 3's first version
         (crag_enc_skinny_gemm, 16-row tiles, eight launches per layer) for A/B measurements."""
         c = self.cfg
-        if (os.environ.get("CRAG_ENC_NO_SKINNY") is not None or c.hidden_size != 2560 or c.q_size != 4096
+        off = os.environ.get("CRAG_ENC_NO_SKINNY") is not None or self.__dict__.get("_skinny_failed", False)
+        if off != self.__dict__.get("_skinny_off", False):
+            self._skinny_off = off
+            self.__dict__.pop("_graphs", None)   # graphs captured over the other set of kernels
+        if (off or c.hidden_size != 2560 or c.q_size != 4096
                 or c.intermediate_size != 9728 or (c.q_size + 2 * c.kv_size) != 6144 or c.head_dim != 128):
             return None
         v1 = os.environ.get("CRAG_ENC_SMALL_V1") is not None
         if self.__dict__.get("_skinny") is None or self.__dict__.get("_skinny_v1") != v1:
             self._skinny = None
             self.__dict__.pop("_graphs", None)   # graphs captured over the other kernels
-            if v1:
-                self._skinny = [{"qkv": ops.skinny_weight(L["qkv"]), "o": ops.skinny_weight(L["o"]),
-                                 "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.skinny_weight(L["down"])}
-                                for L in self.layers]
-            else:
-                self._skinny = [{"qkv": ops.small_weight(L["qkv"], 12), "o": ops.small_weight(L["o"], 10),
-                                 "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.small_weight(L["down"], 10)}
-                                for L in self.layers]
+            try:
+                self._build_skinny(v1)
+            except torch.OutOfMemoryError:
+                # + 100 % of the layer weights does not fit beside what already lives in HBM (an index, its mirror):
+                # the library GEMMs answer short queries from now on -- slower, not an error in the middle of a request
+                self._skinny = None
+                self._skinny_failed = True
+                torch.cuda.empty_cache()
+                return self._skinny_weights()
             self._skinny_v1 = v1
         return self._skinny
+
+    def warm_up(self) -> None:
+        """Build the re-tiled weight copies of the short-query path NOW (at load time, where an allocation failure is a
+        start-up event) instead of inside the first short /retrieve request (seconds of re-tiling under the encoder's lock)."""
+        self._skinny_weights()
+
+    def _build_skinny(self, v1: bool) -> None:
+        if v1:
+            self._skinny = [{"qkv": ops.skinny_weight(L["qkv"]), "o": ops.skinny_weight(L["o"]),
+                             "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.skinny_weight(L["down"])}
+                            for L in self.layers]
+        else:
+            self._skinny = [{"qkv": ops.small_weight(L["qkv"], 12), "o": ops.small_weight(L["o"], 10),
+                             "gate_up": ops.skinny_gate_up_weight(L["gate_up"]), "down": ops.small_weight(L["down"], 10)}
+                            for L in self.layers]
 
     @torch.no_grad()
     def _forward_small_rows(self, x: torch.Tensor, batch: PackedBatch, skinny) -> torch.Tensor:
@@ -401,6 +421,7 @@ class Qwen3Encoder:
             hit["used"] = self.__dict__["_graph_clock"] = self.__dict__.get("_graph_clock", 0) + 1
             return hit
         if len(cache) >= self.SMALL_MAX_GRAPHS:   # drop the least recently used graph (and its private pool)
+            torch.cuda.synchronize(self.device)   # ... once no replay of it can still be running on any stream
             del cache[min(cache, key=lambda k: cache[k]["used"])]
         batch = PackedBatch.build([bucket] * n_seqs, self.device)
         ids = torch.zeros(n_seqs * bucket, dtype=torch.int32, device=self.device)
@@ -413,7 +434,11 @@ class Qwen3Encoder:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.forward_packed(ids, batch)
+        # pinned staging for the two small uploads of a replay + the event of the last upload (an async copy from a
+        # pageable temporary is only safe while the runtime happens to stage it before returning)
         entry = {"graph": graph, "ids": ids, "last_tok": batch.last_tok, "out": out, "batch": batch,
+                 "h_ids": torch.zeros(n_seqs * bucket, dtype=torch.int32).pin_memory(),
+                 "h_last": torch.zeros(n_seqs, dtype=torch.int64).pin_memory(), "uploaded": torch.cuda.Event(),
                  "used": self.__dict__.get("_graph_clock", 0)}
         cache[key] = entry
         return entry
@@ -422,14 +447,17 @@ class Qwen3Encoder:
     def _forward_small(self, token_lists: Sequence[Sequence[int]], lens: Sequence[int], bucket: int) -> torch.Tensor:
         n = len(lens)
         if n * bucket in (16, 32):
-            self._skinny_weights()      # a flip of CRAG_ENC_SMALL_V1 drops the graphs captured over the other kernels
+            self._skinny_weights()      # a flip of CRAG_ENC_SMALL_V1 / CRAG_ENC_NO_SKINNY drops the graphs captured over the other kernels
         g = self._small_graph(n, bucket)
-        host = np.zeros((n, bucket), dtype=np.int32)
+        g["uploaded"].synchronize()            # the copies of the previous replay have left the pinned buffers
+        host = g["h_ids"].numpy().reshape(n, bucket)
+        host.fill(0)
         for i, (tl, m) in enumerate(zip(token_lists, lens)):
             host[i, :m] = np.asarray(tl[:m], dtype=np.int32)
-        last = np.arange(n, dtype=np.int64) * bucket + (np.asarray(lens, dtype=np.int64) - 1)
-        g["ids"].copy_(torch.from_numpy(host.reshape(-1)), non_blocking=True)
-        g["last_tok"].copy_(torch.from_numpy(last), non_blocking=True)
+        g["h_last"].numpy()[:] = np.arange(n, dtype=np.int64) * bucket + (np.asarray(lens, dtype=np.int64) - 1)
+        g["ids"].copy_(g["h_ids"], non_blocking=True)
+        g["last_tok"].copy_(g["h_last"], non_blocking=True)
+        g["uploaded"].record()
         g["graph"].replay()
         return g["out"].clone()
 

@@ -121,6 +121,26 @@ int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, cons
                              const float *cos_sin, int cos_sin_by_token, const int32_t *positions, uint16_t *out,
                              int n_tokens, int hq, int hkv, float eps, float scale, void *stream);
 
+/* ---- the linear layers at 64 / 128 token rows: what the gateway's batcher hands the model (RUNBOOK:304,331-334:
+ * max_batch_size 8, preferred_batch_size [1, 2, 4, 8]) -- csrc/crag_encoder_wide.hip ----
+ *
+ * crag_enc_wide_gemm: partial[s] = X[m_pad, K_s] @ W[n, K_s]^T for the K ranges s = 0 .. splitk-1 (fp32), the weights
+ * streamed once from HBM, the activations staged through LDS; 4 waves = 128 rows of W per workgroup, grid
+ * (n / 128, splitk).
+ *   x   [m_pad, k] bf16, m_pad = 64 or 128 rows allocated and READ (padding rows must hold finite values)
+ *   ww  W in MFMA A-fragment order for v_mfma_f32_32x32x16_bf16: [n/32][k/16][lane = 32 (kk/8) + row][8]
+ *       (torch: W.view(n/32, 32, k/16, 2, 8).permute(0, 2, 3, 1, 4).contiguous())
+ *   partial  crag_enc_wide_partial_bytes(m_pad, n, splitk) bytes of scratch: the accumulators in register order
+ *   n % 128 == 0, k % 128 == 0, 1 <= splitk <= k / 128.
+ * crag_enc_wide_reduce: out = bf16(sum over the splits, in split order) -- one rounding, as an unsplit GEMM --,
+ *   epilogue 0: out [m_rows, n];  epilogue 1 (gate|up: every 32 rows of W are 16 gate rows then the 16 up rows of the
+ *   same features): out [m_rows, n/2] = silu(gate) * up with crag_enc_swiglu's roundings. */
+int64_t crag_enc_wide_partial_bytes(int m_pad, int n, int splitk);
+int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, int m_pad, int n, int k, int splitk,
+                       void *stream);
+int crag_enc_wide_reduce(const float *partial, uint16_t *out, int m_rows, int m_pad, int n, int splitk, int epilogue,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif
