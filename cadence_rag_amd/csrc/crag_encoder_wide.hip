@@ -5,7 +5,19 @@
 //
 // At this size a layer is still a WEIGHT STREAM (202 MB of bf16 weights against <= 128 rows of activations: 25 us at
 // 8 TB/s, 16 GFLOP = 6 us of MFMA time), but the activations no longer fit a wave's registers (crag_encoder_small.hip
-// keeps a wave's K slice of 16 / 32 rows there), and the library's small-M GEMM tiles stream the weights at 1.3 TB/s.
+// keeps a wave's K slice of 16 / 32 rows there), and the library's small-M GEMM tiles stream the weights at 1-3 TB/s.
+//
+// WHERE IT STANDS (round 4, measured as hipGraph replays over rotating weight copies, scripts/probes/wide_gemm_bench.py,
+// profiles/r04_wide_gemm.txt): at 128 rows the four projections of a layer take 112 us through this file and 112 us
+// through hipBLASLt (+ the SwiGLU pass) -- parity; only `down` (K = 9728) is clearly ahead (27.9 vs 39.4 us) and is
+// what the encoder uses it for (Qwen3Encoder, 128-row batches).  At 64 rows the library wins (75 vs 86 us).  What
+// holds it back, by compile-time ablation and rocprofv3: (1) fixed cost per projection: 1.8 us launch + 2.4 us first
+// loads + 5.5 us to write 12.6 MB of fp32 partial tiles (qkv, splitk 4) + a 4-5 us reduce launch, against 8 us of
+// streaming; (2) in the loop hipcc waits vmcnt(0) at the head of every chunk (a load issued in an earlier loop
+// iteration is "pending since unknown") and sinks the next chunk's loads to the bottom of this one, so the ring is one
+// chunk deep whatever the source says: 1.6-1.9 us per 128-column chunk against 0.43 us of MFMAs.  The ways out are
+// counted waits around inline-asm loads (guide 5.7) and partial tiles consumed by the NEXT kernel's prologue instead
+// of a reduce launch; neither is built.
 //
 //   * A workgroup = 4 waves = 128 rows of the weight (each wave its own 32 rows: the A operand of
 //     v_mfma_f32_32x32x16_bf16, streamed once from HBM straight into registers, 8 fragments = 8 KiB in flight per
@@ -87,8 +99,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
     const bool rows_ok = n32 < p.n32;                  // (N is a multiple of 128 for every projection; kept for safety)
 
     // activation staging: piece q of 16 bytes = x[token][128 c + 8 (q & 15) .. + 7], token = q >> 4; a row of a chunk is
-    // 256 contiguous bytes = 16 consecutive threads.  It lands at fragment (k-step (q & 15) >> 1, group token >> 5),
-    // lane 32 ((q & 15) & 1) + (token & 31).
+    // 256 contiguous bytes = 16 consecutive threads.  It lands at fragment (k-step ks = (q & 15) >> 1, group token >> 5),
+    // lane 32 h + (token & 31) with h = q & 1 -- XOR-swizzled inside its 16-lane group by (ks | h << 3): the 16 pieces of
+    // a token (one phase of a ds_write_b128) would otherwise all fall on the same four banks (their addresses differ by
+    // multiples of 512 bytes): a 16-way conflict, 1.7 us of LDS time per chunk against 0.43 us of MFMAs.  The readers
+    // apply the same XOR (a permutation inside each 16-lane phase: their reads stay conflict-free).
     constexpr int PIECES = MG * 32 * 16 / WIDE_THREADS;   // per thread: 4 (64 rows) or 8 (128 rows)
     const u16 *xsrc[PIECES];
     bf16x8 *xdst[PIECES];
@@ -96,9 +111,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
     for (int i = 0; i < PIECES; ++i) {
         const int q = tid + WIDE_THREADS * i, token = q >> 4, piece = q & 15;
         xsrc[i] = p.x + (size_t)token * p.K + piece * 8;
-        xdst[i] = &xs[0][piece >> 1][token >> 5][32 * (piece & 1) + (token & 31)];
+        xdst[i] = &xs[0][piece >> 1][token >> 5][(32 * (piece & 1) + (token & 31)) ^ ((piece >> 1) | ((piece & 1) << 3))];
     }
     constexpr int BUF_STRIDE = WIDE_KS * MG * 64;          // bf16x8 elements between the two LDS buffers
+    const int lsw = lane ^ ((lane >> 5) << 3);             // this lane's slot in a fragment of k-step 0 (k-step s: ^ s)
     const bf16x8 *wsrc = reinterpret_cast<const bf16x8 *>(p.ww) + ((size_t)(rows_ok ? n32 : 0) * (p.K / 16)) * 64 + lane;
 
     f32x16 acc[MG];
@@ -107,36 +123,68 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mg][r] = 0.f;
     if (c0 < c1) {
-        bf16x8 wr[WIDE_KS];
+        // Two chunks of weights in flight per wave (16 loads = 16 KiB; 8 waves per CU: 128 KiB): a chunk's MFMAs are
+        // 0.43 us, an HBM round trip ~2 us -- with ONE chunk in flight the ring drained at every chunk (15 GB/s per
+        // workgroup).  The ring is two register sets used in turn (the chunk loop is unrolled by two).
+        // Every load of the loop is UNCONDITIONAL: past the end a chunk re-loads the last one (an L2 hit nobody uses).
+        // [With `if (c + 1 < c1)` around them hipcc branches around each load and waits vmcnt(0) behind it: the ring ran
+        // one load at a time, 6 GB/s per workgroup.]
+        const int clast = c1 - 1;
+        bf16x8 wa[WIDE_KS], wb[WIDE_KS];
 #pragma unroll
-        for (int s = 0; s < WIDE_KS; ++s) wr[s] = __builtin_nontemporal_load(wsrc + (size_t)(c0 * WIDE_KS + s) * 64);
-        bf16x8 xr[PIECES];
+        for (int s = 0; s < WIDE_KS; ++s) wa[s] = __builtin_nontemporal_load(wsrc + (size_t)(c0 * WIDE_KS + s) * 64);
+        {
+            const int cb = c0 + 1 < c1 ? c0 + 1 : clast;
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) xr[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)c0 * WIDE_BK);
+            for (int s = 0; s < WIDE_KS; ++s) wb[s] = __builtin_nontemporal_load(wsrc + (size_t)(cb * WIDE_KS + s) * 64);
+        }
+        // the activations run TWO chunks ahead as well, in two register sets: a chunk's pieces are requested while the
+        // chunk before the previous one computes and written to LDS a whole chunk later (an L2 round trip is ~1.5 us
+        // under load, a chunk's MFMAs 0.43 us: requested one chunk ahead, every chunk ended waiting for them)
+        bf16x8 xa[PIECES], xb[PIECES];
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) xdst[i][0] = xr[i];
+        for (int i = 0; i < PIECES; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)c0 * WIDE_BK);
+        {
+            const int cb = c0 + 1 < c1 ? c0 + 1 : clast;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) xb[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)cb * WIDE_BK);
+        }
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) xdst[i][0] = xa[i];
         __syncthreads();
         int buf = 0;
-        for (int c = c0; c < c1; ++c) {
-            const bool more = c + 1 < c1;   // uniform
-            if (more) {
+        // chunk c: computes from LDS buffer `buf`, requests chunk c + 2 into `xload`, stages chunk c + 1 (`xstage`,
+        // requested during chunk c - 1) into the other buffer
+        auto chunk = [&](int c, bf16x8 (&wr)[WIDE_KS], bf16x8 (&xload)[PIECES], bf16x8 (&xstage)[PIECES]) {
+            const int cw = c + 2 < c1 ? c + 2 : clast;
 #pragma unroll
-                for (int i = 0; i < PIECES; ++i) xr[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)(c + 1) * WIDE_BK);
-            }
+            for (int i = 0; i < PIECES; ++i)
+                xload[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)cw * WIDE_BK);
+            bf16x8 bq[2][MG];   // the B fragments of a k-step are read one k-step ahead of their MFMAs
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) bq[0][mg] = xs[buf][0][mg][lsw];
 #pragma unroll
             for (int s = 0; s < WIDE_KS; ++s) {
+                if (s + 1 < WIDE_KS) {
+#pragma unroll
+                    for (int mg = 0; mg < MG; ++mg) bq[(s + 1) & 1][mg] = xs[buf][s + 1][mg][lsw ^ (s + 1)];
+                }
                 const bf16x8 wv = wr[s];
-                if (more) wr[s] = __builtin_nontemporal_load(wsrc + (size_t)((c + 1) * WIDE_KS + s) * 64);
+                wr[s] = __builtin_nontemporal_load(wsrc + (size_t)(cw * WIDE_KS + s) * 64);
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg)
-                    acc[mg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xs[buf][s][mg][lane], acc[mg], 0, 0, 0);
+                    acc[mg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, bq[s & 1][mg], acc[mg], 0, 0, 0);
             }
-            if (more) {   // the other buffer was last read before the previous barrier
+            // the other buffer was last read before the previous barrier
 #pragma unroll
-                for (int i = 0; i < PIECES; ++i) xdst[i][(buf ^ 1) * BUF_STRIDE] = xr[i];
-            }
+            for (int i = 0; i < PIECES; ++i)
+                xdst[i][(buf ^ 1) * BUF_STRIDE] = xstage[i];
             __syncthreads();
             buf ^= 1;
+        };
+        for (int c = c0; c < c1; c += 2) {
+            chunk(c, wa, xa, xb);
+            if (c + 1 < c1) chunk(c + 1, wb, xb, xa);   // (uniform)
         }
     }
     if (!rows_ok) return;
