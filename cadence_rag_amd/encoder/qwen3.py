@@ -253,10 +253,29 @@ class Qwen3Encoder:
             self._skinny_v1 = v1
         return self._skinny
 
+    def _wide_down_weights(self):
+        """The `down` projection a second time in the fragment order crag_enc_wide_gemm streams (+ 1.8 GB for the 4B
+        model), for forwards of exactly 128 token rows (8 queries of <= 16 tokens: the gateway's max_batch_size,
+        RUNBOOK:304): the one projection where the weight-streaming kernel beats the library's small-M GEMM (27.9 vs
+        39.4 us per layer, profiles/r04_wide_gemm.txt).  None when the widths are not the 4B model's, CRAG_ENC_NO_WIDE is
+        set or the copy does not fit."""
+        c = self.cfg
+        if (os.environ.get("CRAG_ENC_NO_WIDE") is not None or self.__dict__.get("_wide_failed", False)
+                or c.hidden_size != 2560 or c.intermediate_size != 9728):
+            return None
+        if self.__dict__.get("_wide_down") is None:
+            try:
+                self._wide_down = [ops.wide_weight(L["down"]) for L in self.layers]
+            except torch.OutOfMemoryError:
+                self._wide_down, self._wide_failed = None, True
+                torch.cuda.empty_cache()
+        return self._wide_down
+
     def warm_up(self) -> None:
         """Build the re-tiled weight copies of the short-query path NOW (at load time, where an allocation failure is a
         start-up event) instead of inside the first short /retrieve request (seconds of re-tiling under the encoder's lock)."""
         self._skinny_weights()
+        self._wide_down_weights()
 
     def _build_skinny(self, v1: bool) -> None:
         if v1:
@@ -331,6 +350,7 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
+        wide_down = self._wide_down_weights() if t == 128 else None
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -376,7 +396,11 @@ class Qwen3Encoder:
             ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             gate_up = F.linear(normed, L["gate_up"])
             ops.swiglu(gate_up, act)
-            delta = F.linear(act, L["down"])
+            if wide_down is not None:   # 128 rows: the weight-streaming kernel (csrc/crag_encoder_wide.hip), K split 8 ways
+                delta = ops.wide_gemm(act, wide_down[i], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
+                                      c.hidden_size, 8)
+            else:
+                delta = F.linear(act, L["down"])
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
         if c.pooling == "last":
             # residual + last delta and the final norm for the pooled rows only, inside the pool kernel

@@ -598,6 +598,63 @@ def test_small_attention_fuses_qk_norm_rope_and_causal_attention(gpu, lens):
     assert torch.allclose(got, old.float().cpu().view(t, hq, 128), atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("k,n,swiglu,splitk", [(2560, 6144, False, 4), (4096, 2560, False, 8), (9728, 2560, False, 8),
+                                              (9728, 2560, False, 1), (2560, 19456, True, 1), (2560, 19456, True, 3)])
+@pytest.mark.parametrize("m_rows,m_pad", [(128, 128), (97, 128), (64, 64), (33, 64)])
+def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, splitk, m_rows, m_pad):
+    """crag_enc_wide_gemm + crag_enc_wide_reduce (the gateway's batch sizes, RUNBOOK:304,331-334: up to 8 short queries
+    = 128 token rows) against torch: bf16 operands, fp32 accumulation over K splits added in split order, one rounding;
+    the SwiGLU form against crag_enc_swiglu's arithmetic on the bf16-rounded reference projection; uneven K splits
+    (9728 / 128 = 76 chunks over 8 workgroups); rows beyond m_rows are never written."""
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(k + n + m_rows + splitk)
+    x = torch.randn(m_pad, k, generator=g).to(BF)
+    x[m_rows:] = 0.0                                            # padding rows are read: finite values
+    w = (torch.randn(n, k, generator=g) * 0.02).to(BF)
+    xd, wd = x.to(DEV), w.to(DEV)
+    ref = x[:m_rows].float() @ w.float().t()
+    width = n // 2 if swiglu else n
+    out = torch.full((m_pad + 1, width), 7.0, dtype=BF, device=DEV)
+    ww = ops.wide_gate_up_weight(wd) if swiglu else ops.wide_weight(wd)
+    ops.wide_gemm(xd, ww, out, m_rows, n, splitk, swiglu=swiglu)
+    assert torch.all(out[m_rows:] == 7.0)                       # nothing written behind the real rows
+    got = out[:m_rows].float().cpu()
+    if not swiglu:
+        assert torch.allclose(got, ref, atol=2e-2, rtol=1.2e-2), (got - ref).abs().max()
+        assert (got - ref.to(BF).float()).abs().max() <= 2 * ref.abs().max() * 2 ** -8
+    else:
+        want = torch.empty(m_rows, width, dtype=BF, device=DEV)
+        ops.swiglu(ref.to(BF).to(DEV).contiguous(), want)
+        assert torch.allclose(got, want.float().cpu(), atol=3e-3, rtol=3e-2), (got - want.float().cpu()).abs().max()
+
+
+def test_eight_short_queries_use_the_wide_down_projection_and_match_transformers(gpu, monkeypatch):
+    """The gateway's largest batch (max_batch_size 8, RUNBOOK:304): eight queries of <= 16 tokens = one graph replay
+    over 128 token rows, whose `down` projection is the weight-streaming kernel of crag_encoder_wide.hip.  Real 4B
+    widths, two layers; against transformers' Qwen3Model in fp32 and against the same forward through the library
+    GEMM (CRAG_ENC_NO_WIDE=1)."""
+    model, enc, cfg = _real_width_hf_and_mine()
+    rng = np.random.default_rng(8)
+    lens = [16, 3, 9, 16, 1, 12, 7, 15]
+    token_lists = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
+    monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
+    monkeypatch.delenv("CRAG_ENC_NO_WIDE", raising=False)
+    enc.__dict__.pop("_graphs", None)
+    fast = enc.embed_token_lists(token_lists)
+    assert enc.__dict__.get("_wide_down") is not None
+    assert torch.equal(fast, enc.embed_token_lists(token_lists))
+    monkeypatch.setenv("CRAG_ENC_NO_WIDE", "1")
+    enc.__dict__.pop("_graphs", None)
+    lib = enc.embed_token_lists(token_lists)
+    enc.__dict__.pop("_graphs", None)
+    want = _hf_embed(model, cfg, token_lists, "last")
+    diff = (fast.cpu() - want).abs()
+    assert torch.allclose(fast.norm(dim=1).cpu(), torch.ones(len(lens)), atol=1e-5)
+    assert diff.pow(2).mean().sqrt() <= 6.5e-4 and diff.max() <= 3e-3
+    assert ((fast.cpu() * want).sum(-1)).min() >= 0.9998
+    assert (fast - lib).abs().max() <= 3e-3
+
+
 def test_one_short_query_takes_the_five_launch_layer_and_matches_transformers(gpu, monkeypatch):
     """Real 4B widths, two layers, the shapes of the reference's operating point (one query of <= 16 tokens; also one
     of <= 32 and two of <= 16): embed_token_lists replays the graph of the five-launch layer
