@@ -653,6 +653,9 @@ def compact_line(full: dict) -> dict:
         "hybrid_token_lane_us": _get(full, "hybrid", "split", "token_lane_top50_us"),
         "k100_100k_ms": _get(full, "large_k", "100000x64x100", "ms_per_step"),
         "k100_100k_frac": _get(full, "large_k", "100000x64x100", "roofline", "frac"),
+        "k50_100k_ms": _get(full, "large_k", "100000x64x50", "ms_per_step"),
+        "k100_1m_ms": _get(full, "large_k", "1000000x64x100", "ms_per_step"),
+        "k100_1m_frac": _get(full, "large_k", "1000000x64x100", "roofline", "frac"),
         "nq1_encode_ms": _get(full, "query_path", "nq1", "encode_ms"),
         "nq1_encode_frac": _get(full, "query_path", "nq1", "encode_roofline", "frac"),
         "nq1_request_ms": _get(full, "query_path", "nq1", "request_latency_ms"),
@@ -712,6 +715,7 @@ def main() -> None:
     ap.add_argument("--no-overlap-leg", action="store_true",
                     help="skip the 2- and 3-stream repeats of the headline leg (profiling runs: overlapped launches of "
                          "the same kernel would be averaged into its rocprofv3 duration)")
+    ap.add_argument("--no-large-k", action="store_true", help="skip the top-50 / top-100 legs")
     ap.add_argument("--no-hybrid", action="store_true", help="skip the configs[4] hybrid leg (N = 1, with target_1m)")
     ap.add_argument("--no-query-path", action="store_true",
                     help="skip the reference-operating-point leg (encode 1/8/64 queries -> top-50 + top-10 searches)")
@@ -849,6 +853,17 @@ def main() -> None:
             overlap = {str(n): overlap_leg(index, queries, k, n, args.steps) for n in (2, 3)}
         if index.prefilter_row_bytes() == DIM * 2 and not args.no_fp32_rows_leg:
             fp32_leg = fp32_rows_leg(corpus, ids, queries, k, dev_index, max(200, args.steps // 4), leg["out"], traffic_doc)
+    large_k = {}
+
+    def large_k_leg(ix, q, rows_, kk):
+        """The reference's own dense k (retrieve.py:18-19: 50 chunks; configs[4]: 100) on the same corpus and batch."""
+        lk = search_leg(ix, q, kk, 200, 10, 2, prewarm_s=0.05)
+        return {"ms_per_step": round(min(lk["times"]) / 200 * 1e3, 5), "value": round(int(q.shape[0]) * 200 / min(lk["times"]), 1),
+                "unit": "queries/sec", "roofline": roofline(rows_, int(q.shape[0]), kk, lk, None)}
+
+    if world == 1 and not args.no_large_k:
+        for kk in (50, 100):
+            large_k[f"{rows}x{nq}x{kk}"] = large_k_leg(index, queries, rows, kk)
     target = hybrid = query_path = shared_enc = None
     if world == 1 and not args.no_target_1m and rows_total == ROWS_CONFIG1:
         gpu_ids_100k = leg["out"][0].cpu().numpy()
@@ -882,6 +897,9 @@ def main() -> None:
                 entry["fp32_rows_scan"] = fp32_rows_leg(big, None, q64[:qn].contiguous(), k, dev_index, 150, tl["out"],
                                                         traffic_doc)
             target[name] = entry
+        if not args.no_large_k:
+            for kk in (50, 100):
+                large_k[f"{ROWS_CONFIG2}x64x{kk}"] = large_k_leg(big_index, q64, ROWS_CONFIG2, kk)
         if not args.no_hybrid:
             try:
                 hybrid = hybrid_leg(big_index, ROWS_CONFIG2, dev)
@@ -981,6 +999,8 @@ def main() -> None:
             line["config"]["steps_overlapped_on_streams"] = overlap
         if fp32_leg is not None:
             line["fp32_rows_scan"] = fp32_leg
+        if large_k:
+            line["large_k"] = large_k
         if target is not None:
             line["target_1m"] = target
         if hybrid is not None:

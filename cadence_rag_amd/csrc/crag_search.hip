@@ -1444,12 +1444,16 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_results_kernel(XMergePara
     __syncthreads();
     for (int e = tid; e < p.n_lists * k; e += MERGE_THREADS) {
         const int l = e / k, pos = e - l * k;
+        // the count, the score and the id are requested together (slots beyond a list's count hold its -1 / NaN padding:
+        // read and dropped) -- one memory round trip instead of count -> values
+        const size_t src = (size_t)q * k + pos;
         const int cnt = p.counts[(size_t)l * p.stride_counts + q];
+        const float sc = p.scores[(size_t)l * p.stride_scores + src];
+        const int64_t id = p.ids[(size_t)l * p.stride_ids + src];
         if (pos < cnt) {
-            const size_t src = (size_t)q * k + pos;
             const int idx = atomicAdd(&s_cnt, 1);
-            s_sc[idx] = f2ord(p.scores[(size_t)l * p.stride_scores + src]);
-            s_id[idx] = p.ids[(size_t)l * p.stride_ids + src];
+            s_sc[idx] = f2ord(sc);
+            s_id[idx] = id;
         }
     }
     __syncthreads();
@@ -1927,14 +1931,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     if (threadIdx.x < 32 * NQB) L.qthr[threadIdx.x] = -__builtin_inff();
     if (threadIdx.x == 0) L.n_stage = 0u;
     // the first PF_STASH tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
-    float stash[PF_STASH][RPO];
-    uint32_t stash_row[PF_STASH];
+    float stash[PF_STASH][RPO];   // (their row positions are recomputed at the end: registers are the scarce thing here)
 #pragma unroll
-    for (int t = 0; t < PF_STASH; ++t) {
-        stash_row[t] = 0u;
+    for (int t = 0; t < PF_STASH; ++t)
 #pragma unroll
         for (int e = 0; e < RPO; ++e) stash[t][e] = __uint_as_float(0x7fc00000u);
-    }
     float thr[RPO];    // candidate thresholds of the owned queries (bound - 2 delta)
     uint32_t tau[RPO];            // the bound itself, orderable (0 = none yet)
     uint32_t lmax[RPO][SETS];     // class maxima over this lane's own rows
@@ -2164,7 +2165,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
                 if (ti == t) {
 #pragma unroll
                     for (int e = 0; e < RPO; ++e) stash[t][e] = sc[e];
-                    stash_row[t] = (uint32_t)(row - c.t_begin * 32);
                 }
         } else {
             pf_stage<NQB>(L, o, sc, pass, (uint32_t)(row - c.t_begin * 32), p.flags, p.seq);
@@ -2232,7 +2232,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             bool pass[RPO];
 #pragma unroll
             for (int e = 0; e < RPO; ++e) pass[e] = stash[t][e] >= thr[e];
-            pf_stage<NQB>(L, o, stash[t], pass, stash_row[t], p.flags, p.seq);
+            // (a tile the workgroup does not have left NaN in the stash: nothing passes)
+            pf_stage<NQB>(L, o, stash[t], pass, (uint32_t)(tile_of(c, t) * 32 + j), p.flags, p.seq);
         }
     }
     pf_sift<NQB, true>(p, L, c.t_begin * 32);
