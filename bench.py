@@ -709,6 +709,9 @@ def main() -> None:
                     help="N = 1: which form of the C ABI the timed steps call (async: crag_index_search_async, in stream "
                          "order -- the default: kernel durations are undisturbed; pipelined: crag_index_search_pipelined + "
                          "one crag_index_join per fence).  The other form is timed beside it.")
+    ap.add_argument("--no-other-api", action="store_true",
+                    help="skip the leg that times the other form of the API (profiling runs: its launches of the same "
+                         "kernel overlap on two streams and would be averaged into the rocprofv3 duration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
@@ -804,7 +807,7 @@ def main() -> None:
     leg = search_leg(index, queries, k, args.steps, args.warmup, args.rounds, step_extra, fence_extra, outs,
                      pipelined=pipelined)
     leg_other = None
-    if world == 1:   # the other form beside it; same bits from both
+    if world == 1 and not args.no_other_api:   # the other form beside it; same bits from both
         leg_other = search_leg(index, queries, k, args.steps, min(args.warmup, 20), min(args.rounds, 3),
                                pipelined=not pipelined, prewarm_s=0.05)
         leg["identical_to_other_api"] = all(bool(torch.equal(a, b)) for a, b in zip(leg["out"], leg_other["out"]))

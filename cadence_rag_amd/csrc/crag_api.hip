@@ -367,8 +367,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         fp.sets = k <= 24 ? 1 : (k <= 56 ? 2 : 4);
         fp.pub0 = (k + fp.sets - 1) / fp.sets >= 27 ? 8 : fp.sets;
         fp.cap = cap;
-        fp.derive_lag = ix->env_pf_derive_lag;
-        fp.read_lag = ix->env_pf_read_lag;
+        // exchange lags in tiles: publish -> delegates derive -> every wave reads.  Mirror scan 2 / 4; the scan of the
+        // fp32 rows (twice the time per tile, two stashed tiles) 1 / 2
+        fp.derive_lag = ix->corpus16 ? ix->env_pf_derive_lag : 1;
+        fp.read_lag = ix->corpus16 ? ix->env_pf_read_lag : 2;
         {   // streaming cache policy for a mirror far larger than the Infinity Cache (see prefilter_kernel)
             const int64_t streamed = ix->size * (int64_t)crag::DIM * 2;
             fp.nt = !ix->corpus16 ? 0 : (ix->env_pf_nt >= 0 ? ix->env_pf_nt : (streamed > ix->nt_above_bytes ? 1 : 0));

@@ -1620,7 +1620,9 @@ constexpr int PF_FLUSH_ABOVE = 768;                // staged candidates that tri
 constexpr int PF_STAGE = PF_FLUSH_ABOVE + 2048;    // per-workgroup staging entries in LDS: a tile adds at most 32 x 64
 constexpr int PF_PER = (PF_STAGE + SCAN_THREADS - 1) / SCAN_THREADS;   // staged entries per thread in a sift
 constexpr int PF_TAU_CELL = 128;                   // cell of a query's bound record that holds the DERIVED bound
-constexpr int PF_STASH = 4;                        // tiles scored before the first bound can have arrived
+constexpr int PF_STASH_MIRROR = 4;                 // tiles scored before the first bound can have arrived (mirror scan)
+constexpr int PF_STASH_ROWS = 2;                   // ... scan of the fp32 rows: its tiles take twice as long (the exchange
+                                                   // needs TIME, not tiles: lags 1 / 2), and its registers are full
 // (the lags between a publish, the delegates' derivation and every wave's read -- 2 and 4 tiles -- are PfParams fields)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1931,6 +1933,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
     if (threadIdx.x < 32 * NQB) L.qthr[threadIdx.x] = -__builtin_inff();
     if (threadIdx.x == 0) L.n_stage = 0u;
     // the first PF_STASH tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
+    constexpr int PF_STASH = MIRROR ? PF_STASH_MIRROR : PF_STASH_ROWS;
     float stash[PF_STASH][RPO];   // (their row positions are recomputed at the end: registers are the scarce thing here)
 #pragma unroll
     for (int t = 0; t < PF_STASH; ++t)

@@ -4,7 +4,7 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-RN=${ROUND:-r03}
+RN=${ROUND:-r04}
 O=$R/gpurun_out/$RN
 mkdir -p $O
 # (gpurun takes 7 minutes without output for a hang: a traced bench run is silent for longer)
@@ -13,15 +13,15 @@ HB=$!
 trap "kill $HB 2>/dev/null" EXIT
 python bench.py > $O/bench.json 2> $O/bench.err
 # the driver's own invocation (few steps between synchronisations)
-python bench.py --steps 20 --warmup 5 --no-encode --no-target-1m --no-fp32-rows-leg --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
+python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2>> $O/bench.err
 # two ranks folded onto the one GPU of this box over gloo: the N > 1 code path (shards, exchange, merge, per-rank
 # breakdown) end to end; its times say nothing about xGMI
 CRAG_BENCH_BACKEND=gloo timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 100 --warmup 10 --rounds 2 --no-encode --no-cpu-baseline > $O/bench_n2_gloo_rehearsal.json 2> $O/bench_n2.err || true
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
 # the headline leg alone (in the full command above the 1M legs launch the same kernel template)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -- python3 $R/bench.py --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg --no-overlap-leg > /dev/null 2> $O/stats_headline.err
-B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg --no-overlap-leg"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_headline -- python3 $R/bench.py --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg --no-overlap-leg --no-other-api --no-large-k > /dev/null 2> $O/stats_headline.err
+B="--steps 200 --warmup 20 --rounds 1 --no-cpu-baseline --no-encode --no-target-1m --no-fp32-rows-leg --no-overlap-leg --no-other-api --no-large-k"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64 -- python3 $R/bench.py $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
@@ -46,6 +46,12 @@ python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m32.csv $O/${RN}_
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m64.csv $O/${RN}_pmc_WRITE_SIZE_1m64.csv 1000000x64x10 $O/traffic.json
 # raw traces are large: keep only summaries
 rm -rf $O/pmc_* $O/stats $O/stats_headline $O/trace_small
-cp $O/bench.json $O/${RN}_bench_line.json; cp $O/bench_steps20.json $O/${RN}_bench_line_steps20.json; grep '^{' $O/bench_n2_gloo_rehearsal.json > $O/${RN}_bench_n2_gloo_rehearsal.json || true
+# bench.py prints `DETAIL {...}` (every leg) and then the compact contract line: keep both
+tail -1 $O/bench.json > $O/${RN}_bench_line.json; grep '^DETAIL ' $O/bench.json | cut -c8- > $O/${RN}_bench_detail.json
+tail -1 $O/bench_steps20.json > $O/${RN}_bench_line_steps20.json; grep '^DETAIL ' $O/bench_steps20.json | cut -c8- > $O/${RN}_bench_detail_steps20.json
+grep '^{' $O/bench_n2_gloo_rehearsal.json > $O/${RN}_bench_n2_gloo_rehearsal.json || true
+# top-50 / top-100 probes and the selection block's phase trace
+python scripts/probes/pf_lags.py 2,4 > $O/${RN}_large_k.txt 2>&1 || true
+python scripts/probes/fin_phase_trace.py > $O/${RN}_selection_phases.txt 2>&1 || true
 cat $O/traffic.json
 head -14 $O/${RN}_bench_kernel_stats.csv | cut -c1-160
