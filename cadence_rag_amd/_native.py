@@ -71,6 +71,7 @@ SIGNATURES = {
                                        _c.c_float, _P]),
     "crag_enc_wide_partial_bytes": (_c.c_int64, [_c.c_int, _c.c_int, _c.c_int]),
     "crag_enc_wide_gemm": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "crag_enc_wide_gemm_direct": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "crag_enc_wide_reduce": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "crag_enc_small_attention": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                             _c.c_float, _P]),

@@ -8,16 +8,23 @@
 // keeps a wave's K slice of 16 / 32 rows there), and the library's small-M GEMM tiles stream the weights at 1-3 TB/s.
 //
 // WHERE IT STANDS (round 4, measured as hipGraph replays over rotating weight copies, scripts/probes/wide_gemm_bench.py,
-// profiles/r04_wide_gemm.txt): at 128 rows the four projections of a layer take 112 us through this file and 112 us
-// through hipBLASLt (+ the SwiGLU pass) -- parity; only `down` (K = 9728) is clearly ahead (27.9 vs 39.4 us) and is
-// what the encoder uses it for (Qwen3Encoder, 128-row batches).  At 64 rows the library wins (75 vs 86 us).  What
-// holds it back, by compile-time ablation and rocprofv3: (1) fixed cost per projection: 1.8 us launch + 2.4 us first
-// loads + 5.5 us to write 12.6 MB of fp32 partial tiles (qkv, splitk 4) + a 4-5 us reduce launch, against 8 us of
-// streaming; (2) in the loop hipcc waits vmcnt(0) at the head of every chunk (a load issued in an earlier loop
-// iteration is "pending since unknown") and sinks the next chunk's loads to the bottom of this one, so the ring is one
-// chunk deep whatever the source says: 1.6-1.9 us per 128-column chunk against 0.43 us of MFMAs.  The ways out are
-// counted waits around inline-asm loads (guide 5.7) and partial tiles consumed by the NEXT kernel's prologue instead
-// of a reduce launch; neither is built.
+// profiles/r04_wide_gemm.txt; library = hipBLASLt through torch.matmul, + crag_enc_swiglu for gate|up):
+//   128 rows: qkv 20.4 us (library 15.6), o 18.1 (19.0), gate|up + SwiGLU 30.2 in ONE launch (38.9), down 24.3 (39.4)
+//    64 rows: qkv 15.7 (11.4), o 14.6 (10.9), gate|up + SwiGLU 23.9 (31.6), down 20.7 (21.8)
+// The encoder therefore takes gate|up at 64 / 128 rows and down at 128 rows from here and leaves qkv / o to the
+// library (Qwen3Encoder._wide_weights): 8 queries of 16 tokens 5.48 -> 4.25 ms, 4 queries 4.01 -> 3.76 ms
+// (scripts/probes/small_batch_encode.py).  What was learned on the way (all measured, each cost a factor):
+//   (1) hipcc's own load bookkeeping cannot pipeline this loop: `if (more)` around a load makes it wait vmcnt(0) right
+//       behind that load (6 GB/s per workgroup); without the branch it waits vmcnt(0) at the head of every iteration
+//       for loads issued in an earlier one and sinks the next chunk's loads to the bottom of this one (1.6-1.9 us per
+//       chunk against 0.43 us of MFMAs).  The loads are inline asm with hand-counted waits now.
+//   (2) the 16 pieces of a token row fall on the same four LDS banks unless the staging is swizzled (1.7 us of ds_write
+//       per chunk).
+//   (3) fixed cost per projection: 1.8 us launch + 2.4 us first loads + 5.5 us to write 12.6 MB of fp32 partial tiles
+//       (qkv, splitk 4) + a 4-5 us reduce launch, against 8 us of streaming: the unsplit form writes its output itself
+//       (crag_enc_wide_gemm_direct: gate|up), and what still needs split K (N = 2560: 20 tiles) pays for it.
+// Next: the split-K partials summed in the prologue of the kernel that consumes them (the residual-add + RMSNorm pass
+// for o / down, q/k-norm + RoPE for qkv) instead of a reduce launch; 64-row tiles (2 waves) for the N = 2560 projections.
 //
 //   * A workgroup = 4 waves = 128 rows of the weight (each wave its own 32 rows: the A operand of
 //     v_mfma_f32_32x32x16_bf16, streamed once from HBM straight into registers, 8 fragments = 8 KiB in flight per
@@ -83,9 +90,38 @@ constexpr int WIDE_THREADS = 256;
 struct WideParams {
     const u16 *x;      // [32 MG, K] bf16 activations (rows beyond the real ones are padding: finite, results dropped)
     const u16 *ww;     // weights, [N / 32][K / 16][64 lanes][8]: lane l = row (l & 31), k = 8 (l >> 5) + e
-    float *partial;    // [splitk][N / 32][MG][4][64][4] fp32: the accumulator registers as they are
+    float *partial;    // [splitk][N / 32][MG][4][64][4] fp32: the accumulator registers as they are (NULL: direct output)
+    u16 *out;          // direct output (splitk == 1): [m_rows, ld_out] bf16
     int K, n32, splitk;
+    int m_rows, ld_out, epilogue;
 };
+
+// bf16 output of one wave's 32 x 32 accumulator tile (D[row 8 b + 4 h + c][token] = acc[4 b + c]); epilogue 1: the 32
+// rows are 16 gate rows then the 16 up rows of the same features: out[token][16 tile + f] = silu(gate_f) * up_f
+__device__ __forceinline__ void wide_store(u16 *out, int ld_out, int n32, int token, int h, const f32x4_t (&sum)[4], int epilogue) {
+    if (epilogue == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {   // rows 8 b + 4 h + 0..3
+            uint2 o;
+            o.x = (uint32_t)f2bf(sum[b][0]) | ((uint32_t)f2bf(sum[b][1]) << 16);
+            o.y = (uint32_t)f2bf(sum[b][2]) | ((uint32_t)f2bf(sum[b][3]) << 16);
+            *reinterpret_cast<uint2 *>(out + (size_t)token * ld_out + 32 * n32 + 8 * b + 4 * h) = o;
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {   // gate rows 8 b + 4 h + c, up rows 16 + the same
+            u16 o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gt = bf2f(f2bf(sum[b][c]));
+                const float act = bf2f(f2bf(gt / (1.f + __expf(-gt))));
+                o[c] = f2bf(act * bf2f(f2bf(sum[b + 2][c])));
+            }
+            *reinterpret_cast<uint2 *>(out + (size_t)token * ld_out + 16 * n32 + 8 * b + 4 * h) =
+                make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+    }
+}
 
 template <int MG>
 __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
@@ -123,43 +159,47 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mg][r] = 0.f;
     if (c0 < c1) {
-        // Two chunks of weights in flight per wave (16 loads = 16 KiB; 8 waves per CU: 128 KiB): a chunk's MFMAs are
-        // 0.43 us, an HBM round trip ~2 us -- with ONE chunk in flight the ring drained at every chunk (15 GB/s per
-        // workgroup).  The ring is two register sets used in turn (the chunk loop is unrolled by two).
-        // Every load of the loop is UNCONDITIONAL: past the end a chunk re-loads the last one (an L2 hit nobody uses).
-        // [With `if (c + 1 < c1)` around them hipcc branches around each load and waits vmcnt(0) behind it: the ring ran
-        // one load at a time, 6 GB/s per workgroup.]
+        // TWO chunks in flight per wave, weights (16 x 1 KiB) and activations alike, each in two register sets used in
+        // turn (the chunk loop is unrolled by two).  The loads are inline asm with HAND-COUNTED waits: hipcc's own
+        // bookkeeping waits vmcnt(0) at the head of every loop iteration for a load issued in an earlier one ("pending
+        // since unknown") and sinks the next chunk's loads to the bottom of this one -- whatever the source said, the
+        // ring was one chunk deep: 1.6-1.9 us per chunk against 0.43 us of MFMAs.  (Earlier forms of the same trap:
+        // `if (c + 1 < c1)` around a load makes hipcc wait vmcnt(0) right behind it.)  Every load is therefore
+        // UNCONDITIONAL -- past the end a chunk re-loads the last one, an L2 hit nobody uses -- and the counts are the
+        // same in every iteration.  Program order of the loads of chunk c: NX activation pieces for chunk c + 2, then
+        // one weight fragment for chunk c + 2 behind each k-step's MFMAs.  Hence, in steady state and from the prologue
+        // on:  * the weight fragment of k-step s was requested 2 chunks ago; behind it came 7 - s + (NX + 8) + NX + s
+        //        loads: vmcnt(15 + 2 NX) in front of every k-step;
+        //      * the pieces staged at the end of chunk c (for chunk c + 1) were requested at the top of chunk c - 1;
+        //        behind them came 8 + NX + 8 loads: vmcnt(16 + NX).
+        constexpr int NX = PIECES, W_WAIT = 15 + 2 * NX, X_WAIT = 16 + NX;
         const int clast = c1 - 1;
-        bf16x8 wa[WIDE_KS], wb[WIDE_KS];
+        auto gload = [](bf16x8 &dst, const void *ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
+        auto gload_nt = [](bf16x8 &dst, const void *ptr) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory"); };
+        bf16x8 wa[WIDE_KS], wb[WIDE_KS], xa[PIECES], xb[PIECES];
+        const int cb = c0 + 1 < c1 ? c0 + 1 : clast;
 #pragma unroll
-        for (int s = 0; s < WIDE_KS; ++s) wa[s] = __builtin_nontemporal_load(wsrc + (size_t)(c0 * WIDE_KS + s) * 64);
-        {
-            const int cb = c0 + 1 < c1 ? c0 + 1 : clast;
+        for (int i = 0; i < PIECES; ++i) gload(xa[i], xsrc[i] + (size_t)c0 * WIDE_BK);
 #pragma unroll
-            for (int s = 0; s < WIDE_KS; ++s) wb[s] = __builtin_nontemporal_load(wsrc + (size_t)(cb * WIDE_KS + s) * 64);
-        }
-        // the activations run TWO chunks ahead as well, in two register sets: a chunk's pieces are requested while the
-        // chunk before the previous one computes and written to LDS a whole chunk later (an L2 round trip is ~1.5 us
-        // under load, a chunk's MFMAs 0.43 us: requested one chunk ahead, every chunk ended waiting for them)
-        bf16x8 xa[PIECES], xb[PIECES];
+        for (int s = 0; s < WIDE_KS; ++s) gload_nt(wa[s], wsrc + (size_t)(c0 * WIDE_KS + s) * 64);
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) xa[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)c0 * WIDE_BK);
-        {
-            const int cb = c0 + 1 < c1 ? c0 + 1 : clast;
+        for (int i = 0; i < PIECES; ++i) gload(xb[i], xsrc[i] + (size_t)cb * WIDE_BK);
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) xb[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)cb * WIDE_BK);
-        }
+        for (int s = 0; s < WIDE_KS; ++s) gload_nt(wb[s], wsrc + (size_t)(cb * WIDE_KS + s) * 64);
+        if constexpr (PIECES == 8)
+            asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]) : "n"(X_WAIT));
+        else
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]) : "n"(X_WAIT));
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) xdst[i][0] = xa[i];
         __syncthreads();
         int buf = 0;
-        // chunk c: computes from LDS buffer `buf`, requests chunk c + 2 into `xload`, stages chunk c + 1 (`xstage`,
-        // requested during chunk c - 1) into the other buffer
+        // chunk c: computes from LDS buffer `buf`, requests chunk c + 2 (pieces into `xload`, fragments back into `wr`),
+        // stages chunk c + 1 (`xstage`, requested during chunk c - 1) into the other buffer
         auto chunk = [&](int c, bf16x8 (&wr)[WIDE_KS], bf16x8 (&xload)[PIECES], bf16x8 (&xstage)[PIECES]) {
             const int cw = c + 2 < c1 ? c + 2 : clast;
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i)
-                xload[i] = *reinterpret_cast<const bf16x8 *>(xsrc[i] + (size_t)cw * WIDE_BK);
+            for (int i = 0; i < PIECES; ++i) gload(xload[i], xsrc[i] + (size_t)cw * WIDE_BK);
             bf16x8 bq[2][MG];   // the B fragments of a k-step are read one k-step ahead of their MFMAs
 #pragma unroll
             for (int mg = 0; mg < MG; ++mg) bq[0][mg] = xs[buf][0][mg][lsw];
@@ -169,16 +209,20 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
 #pragma unroll
                     for (int mg = 0; mg < MG; ++mg) bq[(s + 1) & 1][mg] = xs[buf][s + 1][mg][lsw ^ (s + 1)];
                 }
-                const bf16x8 wv = wr[s];
-                wr[s] = __builtin_nontemporal_load(wsrc + (size_t)(cw * WIDE_KS + s) * 64);
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wr[s]) : "n"(W_WAIT));
 #pragma unroll
                 for (int mg = 0; mg < MG; ++mg)
-                    acc[mg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, bq[s & 1][mg], acc[mg], 0, 0, 0);
+                    acc[mg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[s], bq[s & 1][mg], acc[mg], 0, 0, 0);
+                // (behind the MFMAs that read the register: they take their operands at issue, the data lands much later)
+                gload_nt(wr[s], wsrc + (size_t)(cw * WIDE_KS + s) * 64);
             }
             // the other buffer was last read before the previous barrier
+            if constexpr (PIECES == 8)
+                asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xstage[0]), "+v"(xstage[1]), "+v"(xstage[2]), "+v"(xstage[3]), "+v"(xstage[4]), "+v"(xstage[5]), "+v"(xstage[6]), "+v"(xstage[7]) : "n"(X_WAIT));
+            else
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xstage[0]), "+v"(xstage[1]), "+v"(xstage[2]), "+v"(xstage[3]) : "n"(X_WAIT));
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i)
-                xdst[i][(buf ^ 1) * BUF_STRIDE] = xstage[i];
+            for (int i = 0; i < PIECES; ++i) xdst[i][(buf ^ 1) * BUF_STRIDE] = xstage[i];
             __syncthreads();
             buf ^= 1;
         };
@@ -186,8 +230,21 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
             chunk(c, wa, xa, xb);
             if (c + 1 < c1) chunk(c + 1, wb, xb, xa);   // (uniform)
         }
+        // the loads still in flight write registers nobody reads any more: let them land before the registers are reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (!rows_ok) return;
+    if (p.partial == nullptr) {   // unsplit K: round and write the output here -- no partial tiles, no reduce launch
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            const int token = 32 * mg + (lane & 31);
+            f32x4_t sum[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) sum[b] = f32x4_t{acc[mg][4 * b], acc[mg][4 * b + 1], acc[mg][4 * b + 2], acc[mg][4 * b + 3]};
+            if (token < p.m_rows) wide_store(p.out, p.ld_out, n32, token, lane >> 5, sum, p.epilogue);
+        }
+        return;
+    }
     // D[row 8 b + 4 h + c][token j] = acc[4 b + c] of lane (h, j): stored as they are, 16 bytes per lane and b
     f32x4_t *out = reinterpret_cast<f32x4_t *>(p.partial) + (((size_t)split * p.n32 + n32) * MG) * 4 * 64 + lane;
 #pragma unroll
@@ -222,28 +279,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_reduce_kernel(WideReducePar
         for (int b = 0; b < 4; ++b) sum[b] += src[(size_t)s * split_stride + b * 64];
     }
     if (token >= p.m_rows) return;
-    if (p.epilogue == 0) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {   // rows 8 b + 4 h + 0..3
-            uint2 o;
-            o.x = (uint32_t)f2bf(sum[b][0]) | ((uint32_t)f2bf(sum[b][1]) << 16);
-            o.y = (uint32_t)f2bf(sum[b][2]) | ((uint32_t)f2bf(sum[b][3]) << 16);
-            *reinterpret_cast<uint2 *>(p.out + (size_t)token * p.ld_out + 32 * n32 + 8 * b + 4 * h) = o;
-        }
-    } else {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {   // gate rows 8 b + 4 h + c, up rows 16 + the same
-            u16 o[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float gt = bf2f(f2bf(sum[b][c]));
-                const float act = bf2f(f2bf(gt / (1.f + __expf(-gt))));
-                o[c] = f2bf(act * bf2f(f2bf(sum[b + 2][c])));
-            }
-            *reinterpret_cast<uint2 *>(p.out + (size_t)token * p.ld_out + 16 * n32 + 8 * b + 4 * h) =
-                make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
-        }
-    }
+    wide_store(p.out, p.ld_out, n32, token, h, sum, p.epilogue);
 }
 
 }  // namespace
@@ -266,6 +302,8 @@ int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, in
     p.x = x;
     p.ww = ww;
     p.partial = partial;
+    p.out = nullptr;
+    p.m_rows = p.ld_out = p.epilogue = 0;
     p.K = k;
     p.n32 = n / 32;
     p.splitk = splitk;
@@ -273,6 +311,31 @@ int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, in
     if (m_pad == 64) hipLaunchKernelGGL(wide_gemm_kernel<2>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wide_gemm_kernel<4>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
     return whip_ok("wide_gemm");
+}
+
+int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *out, int m_rows, int m_pad, int n, int k,
+                              int epilogue, void *stream) {
+    if (!x || !ww || !out) return wfail("wide_gemm_direct: NULL pointer");
+    if (m_pad != 64 && m_pad != 128) return wfail("wide_gemm_direct: m_pad must be 64 or 128 (got %d)", m_pad);
+    if (m_rows <= 0 || m_rows > m_pad) return wfail("wide_gemm_direct: 0 < m_rows <= m_pad");
+    if (n <= 0 || n % 128) return wfail("wide_gemm_direct: n must be a multiple of 128 (got %d)", n);
+    if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm_direct: k must be a multiple of %d (got %d)", WIDE_BK, k);
+    if (epilogue != 0 && epilogue != 1) return wfail("wide_gemm_direct: epilogue must be 0 or 1");
+    WideParams p;
+    p.x = x;
+    p.ww = ww;
+    p.partial = nullptr;
+    p.out = out;
+    p.m_rows = m_rows;
+    p.ld_out = epilogue ? n / 2 : n;
+    p.epilogue = epilogue;
+    p.K = k;
+    p.n32 = n / 32;
+    p.splitk = 1;
+    const dim3 grid((unsigned)(n / 128), 1u);
+    if (m_pad == 64) hipLaunchKernelGGL(wide_gemm_kernel<2>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wide_gemm_kernel<4>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    return whip_ok("wide_gemm_direct");
 }
 
 int crag_enc_wide_reduce(const float *partial, uint16_t *out, int m_rows, int m_pad, int n, int splitk, int epilogue,

@@ -183,6 +183,10 @@ def wide_gemm(x: torch.Tensor, ww: torch.Tensor, out: torch.Tensor, m_rows: int,
     buffer of >= splitk * n * m_pad elements (one per device is kept otherwise: calls on one stream reuse it in order)."""
     _req(x, torch.bfloat16, "x"); _req(ww, torch.bfloat16, "ww"); _req(out, torch.bfloat16, "out")
     m_pad, k = x.shape
+    if int(splitk) == 1:   # one launch: the GEMM kernel rounds and writes the output itself
+        _native.check(_native.load().crag_enc_wide_gemm_direct(_p(x), _p(ww), _p(out), int(m_rows), int(m_pad), int(n), int(k),
+                                                               1 if swiglu else 0, _stream()), "crag_enc_wide_gemm_direct")
+        return out
     need = int(splitk) * int(n) * int(m_pad)
     if scratch is None:
         scratch = _wide_scratch.get(x.device)

@@ -253,29 +253,35 @@ class Qwen3Encoder:
             self._skinny_v1 = v1
         return self._skinny
 
-    def _wide_down_weights(self):
-        """The `down` projection a second time in the fragment order crag_enc_wide_gemm streams (+ 1.8 GB for the 4B
-        model), for forwards of exactly 128 token rows (8 queries of <= 16 tokens: the gateway's max_batch_size,
-        RUNBOOK:304): the one projection where the weight-streaming kernel beats the library's small-M GEMM (27.9 vs
-        39.4 us per layer, profiles/r04_wide_gemm.txt).  None when the widths are not the 4B model's, CRAG_ENC_NO_WIDE is
-        set or the copy does not fit."""
+    def _wide_weights(self):
+        """gate|up and down a second time in the fragment order crag_enc_wide_gemm streams (+ 5.4 GB for the 4B model),
+        for forwards of exactly 64 or 128 token rows (3 to 8 queries of <= 16 tokens: the gateway's batch sizes,
+        RUNBOOK:304,331-334).  Those are the projections where the weight-streaming kernel beats the library's small-M
+        GEMM (profiles/r04_wide_gemm.txt, per layer at 128 rows: gate|up + SwiGLU 30.2 vs 38.9 us in ONE launch, down 24.3
+        vs 39.4; at 64 rows gate|up 23.9 vs 31.6); qkv and o stay with the library.  None when the widths are not the 4B
+        model's, CRAG_ENC_NO_WIDE is set or the copies do not fit."""
         c = self.cfg
-        if (os.environ.get("CRAG_ENC_NO_WIDE") is not None or self.__dict__.get("_wide_failed", False)
-                or c.hidden_size != 2560 or c.intermediate_size != 9728):
+        off = os.environ.get("CRAG_ENC_NO_WIDE") is not None or self.__dict__.get("_wide_failed", False)
+        if off != self.__dict__.get("_wide_off", False):
+            self._wide_off = off
+            self.__dict__.pop("_graphs", None)   # graphs captured over the other set of kernels
+        if off or c.hidden_size != 2560 or c.intermediate_size != 9728:
             return None
-        if self.__dict__.get("_wide_down") is None:
+        if self.__dict__.get("_wide") is None:
             try:
-                self._wide_down = [ops.wide_weight(L["down"]) for L in self.layers]
+                self._wide = [{"gate_up": ops.wide_gate_up_weight(L["gate_up"]), "down": ops.wide_weight(L["down"])}
+                              for L in self.layers]
             except torch.OutOfMemoryError:
-                self._wide_down, self._wide_failed = None, True
+                self._wide, self._wide_failed = None, True
                 torch.cuda.empty_cache()
-        return self._wide_down
+                return self._wide_weights()
+        return self._wide
 
     def warm_up(self) -> None:
         """Build the re-tiled weight copies of the short-query path NOW (at load time, where an allocation failure is a
         start-up event) instead of inside the first short /retrieve request (seconds of re-tiling under the encoder's lock)."""
         self._skinny_weights()
-        self._wide_down_weights()
+        self._wide_weights()
 
     def _build_skinny(self, v1: bool) -> None:
         if v1:
@@ -350,7 +356,7 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
-        wide_down = self._wide_down_weights() if t == 128 else None
+        wide = self._wide_weights() if t in (64, 128) else None
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -394,10 +400,13 @@ class Qwen3Encoder:
                 continue
             delta = F.linear(attn, L["o"])
             ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
-            gate_up = F.linear(normed, L["gate_up"])
-            ops.swiglu(gate_up, act)
-            if wide_down is not None:   # 128 rows: the weight-streaming kernel (csrc/crag_encoder_wide.hip), K split 8 ways
-                delta = ops.wide_gemm(act, wide_down[i], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
+            if wide is not None:   # 64 / 128 rows: gate|up + SwiGLU as ONE weight-streaming launch (crag_encoder_wide.hip)
+                ops.wide_gemm(normed, wide[i]["gate_up"], act, t, 2 * c.intermediate_size, 1, swiglu=True)
+            else:
+                gate_up = F.linear(normed, L["gate_up"])
+                ops.swiglu(gate_up, act)
+            if wide is not None and t == 128:   # ... and down with K split 8 ways (at 64 rows the library's GEMM is level)
+                delta = ops.wide_gemm(act, wide[i]["down"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
                                       c.hidden_size, 8)
             else:
                 delta = F.linear(act, L["down"])
@@ -470,6 +479,8 @@ class Qwen3Encoder:
     @torch.no_grad()
     def _forward_small(self, token_lists: Sequence[Sequence[int]], lens: Sequence[int], bucket: int) -> torch.Tensor:
         n = len(lens)
+        if n * bucket in (64, 128):
+            self._wide_weights()        # (a flip of CRAG_ENC_NO_WIDE drops the graphs captured over the other kernels)
         if n * bucket in (16, 32):
             self._skinny_weights()      # a flip of CRAG_ENC_SMALL_V1 / CRAG_ENC_NO_SKINNY drops the graphs captured over the other kernels
         g = self._small_graph(n, bucket)

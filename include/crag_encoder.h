@@ -138,6 +138,10 @@ int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, cons
 int64_t crag_enc_wide_partial_bytes(int m_pad, int n, int splitk);
 int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, int m_pad, int n, int k, int splitk,
                        void *stream);
+/* The unsplit form in ONE launch: out = bf16(X @ W^T) (epilogue 0) or silu(gate) * up (epilogue 1) written by the GEMM
+ * kernel itself -- no partial tiles, no reduce launch; n / 128 workgroups (gate|up: 152). */
+int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *out, int m_rows, int m_pad, int n, int k,
+                              int epilogue, void *stream);
 int crag_enc_wide_reduce(const float *partial, uint16_t *out, int m_rows, int m_pad, int n, int splitk, int epilogue,
                          void *stream);
 
