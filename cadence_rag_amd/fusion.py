@@ -282,15 +282,15 @@ class HybridSearcher:
     lane order bm25 -> tech_tokens -> dense."""
 
     def __init__(self, index, tech_index: "TechTokenIndex | None" = None, *, dense_k: int = 50, tech_k: int = 50,
-                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False, overlap_lanes: bool = False) -> None:
+                 rrf_k: int = DEFAULT_RRF_K, verify_tokens: bool = False, overlap_lanes: bool = True) -> None:
         """verify_tokens: run the exact-token lane's host-side string check (a blocking D2H copy per step); off by
         default so that a step only enqueues work on the caller's stream.
-        overlap_lanes: run the exact-token lane on a side stream beside the dense scan (forked from the caller's
-        stream behind the scan's launch, joined in front of the fusion kernel; same results, tested).  OFF by default:
-        measured on MI355X in alternating rounds (1M chunks, 64 queries, dense top-100) 0.440 ms per step against
-        0.441 with the lanes in series -- the scan holds every CU's whole register file (one 512-thread workgroup
-        per CU), so the token lane's workgroups only start when scan workgroups retire: nothing to win, and two
-        more events per step."""
+        overlap_lanes: run the exact-token lane on a side stream beside the dense search (forked from the caller's
+        stream behind the scan's launch, joined in front of the fusion kernel; same results, tested).  ON by default
+        since round 4: measured on MI355X in alternating rounds (1M chunks, 64 queries, dense top-100) 0.395 ms per
+        step against 0.421 with the lanes in series.  [Round 3 measured 0.440 vs 0.441 and left it off: the scan holds
+        every CU (one 512-thread workgroup each), so the token lane's workgroups start only as scan workgroups retire;
+        what they overlap with now is the selection launch, which occupies a quarter of the chip for ~22 us.]"""
         self.index, self.tech = index, tech_index
         self.verify_tokens = bool(verify_tokens)
         self.overlap_lanes = bool(overlap_lanes)
