@@ -26,6 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64 -- python3 $R/bench.py $B > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_1m64 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 64 --steps 60 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_100k64k100 -- python3 $R/bench.py $B --topk 100 > /dev/null 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $O/pmc_sq_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq2_1m32 -- python3 $R/bench.py $B --rows-per-gpu 1000000 --queries 32 --steps 60 > /dev/null 2>&1
@@ -36,7 +37,7 @@ f=$(find $O/trace_small -name "*kernel_trace.csv" | head -1)
 if [ -n "$f" ]; then ( grep tokens $O/small_encode_trace.log; python scripts/probes/trace_gaps_enc.py $f ) > $O/${RN}_small_layer_kernel_trace.txt 2>&1 || true; fi
 python scripts/pmc_summary.py stats $O/stats $O/${RN}_bench_kernel_stats.csv
 python scripts/pmc_summary.py stats $O/stats_headline $O/${RN}_headline_leg_kernel_stats.csv
-for w in 100k64 1m32 1m64; do
+for w in 100k64 1m32 1m64 100k64k100; do
   for c in FETCH_SIZE WRITE_SIZE; do python scripts/pmc_summary.py pmc $O/pmc_${c}_$w $O/${RN}_pmc_${c}_$w.csv; done
 done
 python scripts/pmc_summary.py pmc $O/pmc_sq_1m32 $O/${RN}_prefilter_1m_q32_sq_counters.csv
@@ -44,6 +45,7 @@ python scripts/pmc_summary.py pmc $O/pmc_sq2_1m32 $O/${RN}_prefilter_1m_q32_sq_c
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_100k64.csv $O/${RN}_pmc_WRITE_SIZE_100k64.csv 100000x64x10 $O/traffic.json
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m32.csv $O/${RN}_pmc_WRITE_SIZE_1m32.csv 1000000x32x10 $O/traffic.json
 python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_1m64.csv $O/${RN}_pmc_WRITE_SIZE_1m64.csv 1000000x64x10 $O/traffic.json
+python scripts/pmc_summary.py traffic $O/${RN}_pmc_FETCH_SIZE_100k64k100.csv $O/${RN}_pmc_WRITE_SIZE_100k64k100.csv 100000x64x100 $O/traffic.json
 # raw traces are large: keep only summaries
 rm -rf $O/pmc_* $O/stats $O/stats_headline $O/trace_small
 # bench.py prints `DETAIL {...}` (every leg) and then the compact contract line: keep both
