@@ -93,15 +93,15 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
     oi, osc, oc = outs
     stream = torch.cuda.current_stream().cuda_stream
 
-    if pipelined:   # two output sets: consecutive searches run on two streams at once
-        alt = (torch.empty_like(oi), torch.empty_like(osc), torch.empty_like(oc))
+    if pipelined:   # an output set per internal stream (up to 4): consecutive searches run on several streams at once
+        alts = [(oi, osc, oc)] + [(torch.empty_like(oi), torch.empty_like(osc), torch.empty_like(oc)) for _ in range(3)]
+        alt = alts[1]
         flip = [0]
 
     def step():
         if pipelined:
-            flip[0] ^= 1
-            o = (oi, osc, oc) if flip[0] else alt
-            index.search_pipelined(queries, k, *o, stream=stream, inputs_ready=True)
+            flip[0] = (flip[0] + 1) % 4
+            index.search_pipelined(queries, k, *alts[flip[0]], stream=stream, inputs_ready=True)
         else:
             index.search_async(queries, k, oi, osc, oc, stream=stream)
         if step_extra is not None:
@@ -991,7 +991,7 @@ def main() -> None:
             name = "in_order_api" if pipelined else "pipelined_api"
             line["config"]["identical_to_other_api"] = leg.get("identical_to_other_api")
             line[name] = {"api": ("crag_index_search_async" if pipelined else
-                                  "crag_index_search_pipelined + crag_index_join per fence (two streams of the index's own)"),
+                                  "crag_index_search_pipelined + crag_index_join per fence (three streams of the index's own)"),
                           "value": round(nq * args.steps / t_o[0], 2), "unit": "queries/sec",
                           "ms_per_step": round(t_o[0] / args.steps * 1e3, 5),
                           "ms_per_step_median": round(statistics.median(t_o) / args.steps * 1e3, 5),

@@ -107,10 +107,12 @@ struct crag_index {
         bool dirty = false;
         uint64_t last_use = 0;
     } ws[MAX_WS];
-    // crag_index_search_pipelined: two streams of the index's own, used in turn
-    hipStream_t pipe[2] = {nullptr, nullptr};
-    hipEvent_t pipe_fork[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr};
-    bool pipe_pending[2] = {false, false};
+    // crag_index_search_pipelined: streams of the index's own, used in turn (3 by default; CRAG_PIPE_STREAMS=1..4)
+    static constexpr int MAX_PIPE = 4;
+    int n_pipe = 3;
+    hipStream_t pipe[MAX_PIPE] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pipe_fork[MAX_PIPE] = {nullptr, nullptr, nullptr, nullptr}, pipe_done[MAX_PIPE] = {nullptr, nullptr, nullptr, nullptr};
+    bool pipe_pending[MAX_PIPE] = {false, false, false, false};
     unsigned pipe_next = 0;
     uint64_t use_clock = 0;
     bool multi_stream = false;  // more than one stream has searched this index
@@ -536,6 +538,10 @@ int crag_index_create(int device, int dim, int64_t capacity, crag_index **out) {
         }
     }
     if (const char *v = getenv("CRAG_TEST_FAIL_AFTER_SCAN")) ix->env_fail_after_scan = atoll(v);
+    if (const char *v = getenv("CRAG_PIPE_STREAMS")) {
+        const int n = atoi(v);
+        if (n >= 1 && n <= crag_index::MAX_PIPE) ix->n_pipe = n;
+    }
     if (const char *v = getenv("CRAG_PF_NT_ABOVE_MB")) ix->nt_above_bytes = (int64_t)atoll(v) << 20;
     if (!ix->env_no_prefilter && getenv("CRAG_NO_FP16_MIRROR") == nullptr) {
         // + 2 KiB per row beside the 4 KiB fp32 row: the prefilter scan then streams half the bytes.  Padding rows
@@ -582,7 +588,7 @@ int crag_index_destroy(crag_index *ix) {
     }
     if (ix->irregular_dev) (void)hipFree(ix->irregular_dev);
     if (ix->phase_trace) (void)hipFree(ix->phase_trace);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < crag_index::MAX_PIPE; ++i) {
         if (ix->pipe_fork[i]) (void)hipEventDestroy(ix->pipe_fork[i]);
         if (ix->pipe_done[i]) (void)hipEventDestroy(ix->pipe_done[i]);
         if (ix->pipe[i]) (void)hipStreamDestroy(ix->pipe[i]);
@@ -800,13 +806,20 @@ int crag_index_search_pipelined(crag_index *ix, const float *d_queries, int nq, 
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard guard(ix->device);
     if (!ix->pipe[0]) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < ix->n_pipe; ++i) {
             HIP_TRY(hipStreamCreateWithFlags(&ix->pipe[i], hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ix->pipe_fork[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ix->pipe_done[i], hipEventDisableTiming));
         }
     }
-    const int i = (int)(ix->pipe_next++ & 1u);
+    // Overlap pays for the searches whose small kernels are a large share of the step -- k <= 24 (one class set): 100 000
+    // x 64, k = 10: 40.2 us per step on three streams against 47.7 in order; 1M: 316 against 322 -- and costs for larger k,
+    // whose scans disturb each other's bound exchange (k = 100 at 100 000 rows: 74-80 us against 71).  Those run in
+    // stream order on the caller's stream (the join then has nothing to wait for).
+    if (k > 24 || ix->n_pipe <= 1)
+        return search_device(ix, d_queries, nq, k, d_row_mask, mask_stride, d_out_ids, d_out_scores, d_out_counts,
+                             (hipStream_t)stream);
+    const int i = (int)(ix->pipe_next++ % (unsigned)ix->n_pipe);
     if (!(flags & CRAG_PIPE_INPUTS_READY)) {
         HIP_TRY(hipEventRecord(ix->pipe_fork[i], (hipStream_t)stream));
         HIP_TRY(hipStreamWaitEvent(ix->pipe[i], ix->pipe_fork[i], 0));
@@ -823,7 +836,7 @@ int crag_index_join(crag_index *ix, void *stream) {
     if (!ix) return fail(CRAG_EINVAL, "index is NULL");
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard guard(ix->device);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < ix->n_pipe; ++i)
         if (ix->pipe_pending[i]) {
             HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->pipe_done[i], 0));
             ix->pipe_pending[i] = false;

@@ -1709,6 +1709,7 @@ struct PfLds {
     float qthr[32 * NQB];                        // the owners' current candidate thresholds (they only rise)
     uint32_t qcount[32 * NQB], qbase[32 * NQB], qfill[32 * NQB];
     uint32_t n_stage;
+    uint32_t need[NQB];                          // bit q: a wave found no bound for query q of the pass (emergency derivation)
     uint32_t want_flush[2][SCAN_WAVES];          // [slab buffer][wave]: the wave saw the staging buffer fill up
 };
 
@@ -1931,6 +1932,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             if (o.qg0 + e < p.nq && qi[e] > 0.f) o.okmask |= 1u << e;
     }
     if (threadIdx.x < 32 * NQB) L.qthr[threadIdx.x] = -__builtin_inff();
+    if (threadIdx.x < NQB) L.need[threadIdx.x] = 0u;
     if (threadIdx.x == 0) L.n_stage = 0u;
     // the first PF_STASH tiles' scores (NaN = not eligible): scored before any bound can have arrived, judged at the end
     constexpr int PF_STASH = MIRROR ? PF_STASH_MIRROR : PF_STASH_ROWS;
@@ -2128,10 +2130,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             }
         }
         if (ti == der_base + PF_DERIVE_LAG) der_base = pf_next_pub(der_base, c.n_tiles, PF_READ_LAG);
+        {   // emergency derivations asked for on the previous tile (see below): wave w takes the flagged queries = w mod 8
+            uint32_t need[NQB];
+#pragma unroll
+            for (int i = 0; i < NQB; ++i) need[i] = __builtin_amdgcn_readfirstlane((int)L.need[i]);
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < NQB; ++i) any = any || need[i] != 0u;
+            if (any) {   // (uniform; never taken while the delegates keep up)
+#pragma unroll
+                for (int i = 0; i < NQB; ++i) {
+                    uint32_t mine = need[i] & (0x01010101u << w);   // queries 32 i + w, + 8, + 16, + 24
+                    while (mine) {
+                        const int b = __builtin_ctz(mine);
+                        mine &= mine - 1u;
+                        uint32_t more[DS];
+                        load_cells(32 * i + b, more);
+                        derive_cells(32 * i + b, more);
+                    }
+                    if (lane == 0 && (need[i] & (0x01010101u << w))) atomicAnd(&L.need[i], ~(need[i] & (0x01010101u << w)));
+                }
+            }
+        }
         if (rd) {
             take_taus(tq);
-            // no bound yet for one of the queries (its delegate is behind): ask again on the next tile
+            // No bound yet for one of the queries: its delegates are not running yet (a scan that shares the GPU with
+            // another search's kernels gets its workgroups a few at a time, and the delegates of a query are four
+            // particular workgroups).  Without a bound the wave passes EVERY row of the coming tiles and the search ends
+            // in the overflow fallback (measured: two scans of 1M rows started together, 1.9 ms per search instead of
+            // 0.33).  So the wave asks ITS OWN workgroup for an emergency derivation (L.need: one bit per query of the
+            // pass; the waves share the flagged queries on the next tile, below) and reads again on the tile after.
             if (any_without_bound()) {
+                if (j == 0) {
+#pragma unroll
+                    for (int e = 0; e < RPO; ++e)
+                        if (((o.okmask >> e) & 1u) && tau[e] == 0u) atomicOr(&L.need[(o.ql0 + e) >> 5], 1u << ((o.ql0 + e) & 31));
+                }
                 next_read = ti + 1;
             } else {
                 rd_base = pf_next_pub(rd_base, c.n_tiles, PF_READ_LAG);

@@ -114,10 +114,11 @@ int crag_index_search_async(crag_index *ix, const float *d_queries, int nq, int 
                             float *d_out_scores, int32_t *d_out_counts, void *stream);
 
 /* Throughput form of crag_index_search_async for ONE caller stream that issues a run of INDEPENDENT searches (a
- * batch job: the eval harness, bulk re-ranking, bench.py): consecutive calls alternate between two streams the index
- * owns -- each with its own workspace --, so that the query preparation and the scan of search i + 1 run beside the
- * selection of search i; an in-order stream leaves the chip idle during those small kernels (14 of 48 us per search
- * at 100 000 rows x 64 queries).  What the caller gives up is the stream order between a search and what follows:
+ * batch job: the eval harness, bulk re-ranking, bench.py): consecutive calls take turns on three streams the index
+ * owns (CRAG_PIPE_STREAMS=1..4) -- each with its own workspace --, so that the small kernels of one search (query
+ * preparation, selection) run beside the scan of another; an in-order stream leaves most of the chip idle during them
+ * (12 of 48 us per search at 100 000 rows x 64 queries, k = 10: 40 us per step pipelined).  Searches with k > 24 gain
+ * nothing from it (their scans disturb each other's bound exchange) and run in stream order on the caller's stream.  What the caller gives up is the stream order between a search and what follows:
  *   * the OUTPUTS of a call are defined on `stream` only behind crag_index_join(ix, stream) (which makes `stream`
  *     wait for every pipelined search issued so far; it does not block the host);
  *   * flags & CRAG_PIPE_INPUTS_READY: the caller states that queries / row_mask are complete in memory when the call
