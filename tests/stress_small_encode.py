@@ -1,5 +1,5 @@
-"""Developer stress run (GPU box): random short token lists whose padded shapes are 16 or 32 rows -- the five-launch
-layer behind a graph replay (csrc/crag_encoder_small.hip) against the eager packed forward through the library GEMMs
+"""Developer stress run (GPU box): random short token lists whose padded shapes are 16 / 32 rows -- the five-launch
+layer behind a graph replay (csrc/crag_encoder_small.hip) -- or 64 / 128 rows (the wide projections, crag_encoder_wide.hip) against the eager packed forward through the library GEMMs
 and the unfused kernels, at the 4B widths (4 layers).  Not collected by pytest."""
 import os, sys, time
 import numpy as np
@@ -16,7 +16,7 @@ cfg = Qwen3Config(num_layers=4, vocab_size=4096)
 enc = Qwen3Encoder.random_init(cfg, seed=11, device=dev)
 worst, fails, t0 = 0.0, 0, time.time()
 for case in range(n_cases):
-    lens, toks = random_short_token_lists(rng, cfg.vocab_size)
+    lens, toks = random_short_token_lists(rng, cfg.vocab_size, shapes=("1x16", "1x32", "2x16", "4x16", "8x16", "1x64", "1x128", "2x64", "4x32"))
     os.environ.pop("CRAG_ENC_NO_GRAPH", None); os.environ.pop("CRAG_ENC_NO_SKINNY", None)
     fast = enc.embed_token_lists(toks)
     again = enc.embed_token_lists(toks)

@@ -41,8 +41,11 @@ def test_twenty_random_short_encodes_replay_equals_eager(gpu, monkeypatch):
     rng = np.random.default_rng(3)
     cfg = Qwen3Config(num_layers=4, vocab_size=4096)
     enc = Qwen3Encoder.random_init(cfg, seed=11, device=torch.device("cuda", 0))
-    for case in range(20):
-        lens, toks = random_short_token_lists(rng, cfg.vocab_size)
+    for case in range(28):
+        # 20 cases of the 16 / 32-row shapes (the five-launch layer), 8 of the 64 / 128-row shapes (the gateway's batches
+        # of 3 to 8 queries: gate|up and down through the wide weight-streaming kernels)
+        lens, toks = random_short_token_lists(rng, cfg.vocab_size) if case < 20 else \
+            random_short_token_lists(rng, cfg.vocab_size, shapes=("4x16", "8x16", "1x64", "1x128", "2x64", "4x32"))
         monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
         monkeypatch.delenv("CRAG_ENC_NO_SKINNY", raising=False)
         fast = enc.embed_token_lists(toks)
