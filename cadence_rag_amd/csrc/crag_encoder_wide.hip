@@ -9,10 +9,10 @@
 //
 // WHERE IT STANDS (round 4, measured as hipGraph replays over rotating weight copies, scripts/probes/wide_gemm_bench.py,
 // profiles/r04_wide_gemm.txt; library = hipBLASLt through torch.matmul, + crag_enc_swiglu for gate|up):
-//   128 rows: qkv 20.4 us (library 15.6), o 18.1 (19.0), gate|up + SwiGLU 30.2 in ONE launch (38.9), down 24.3 (39.4)
-//    64 rows: qkv 15.7 (11.4), o 14.6 (10.9), gate|up + SwiGLU 23.9 (31.6), down 20.7 (21.8)
-// The encoder therefore takes gate|up at 64 / 128 rows and down at 128 rows from here and leaves qkv / o to the
-// library (Qwen3Encoder._wide_weights): 8 queries of 16 tokens 5.48 -> 4.25 ms, 4 queries 4.01 -> 3.76 ms
+//   128 rows: qkv 20.1 us (library 15.4), o 17.7 (18.8), gate|up + SwiGLU 29.0 in ONE launch (37.2), down 24.1 (39.3)
+//    64 rows: qkv 12.8 (11.3), o 11.4 (10.9), gate|up + SwiGLU 23.5 (30.9), down 18.9 (21.7)
+// The encoder therefore takes gate|up and down at 64 / 128 rows from here and leaves qkv / o to the library
+// (Qwen3Encoder._wide_weights): 8 queries of 16 tokens 5.47 -> 4.25 ms, 4 queries 4.03 -> 3.51 ms
 // (scripts/probes/small_batch_encode.py).  What was learned on the way (all measured, each cost a factor):
 //   (1) hipcc's own load bookkeeping cannot pipeline this loop: `if (more)` around a load makes it wait vmcnt(0) right
 //       behind that load (6 GB/s per workgroup); without the branch it waits vmcnt(0) at the head of every iteration
@@ -47,6 +47,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/crag_encoder.h"
 
@@ -83,9 +84,8 @@ int whip_ok(const char *what) {
 __device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((uint32_t)v << 16); }
 __device__ __forceinline__ u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 
-constexpr int WIDE_BK = 128;            // activation columns per LDS chunk
-constexpr int WIDE_KS = WIDE_BK / 16;   // k-steps (MFMAs per token group) per chunk = the weight ring's depth
-constexpr int WIDE_THREADS = 256;
+constexpr int WIDE_BK = 128;            // K granularity of the interface (chunks are 128 or 64 columns inside)
+constexpr int WIDE_THREADS = 256;       // (the reduce kernel's block)
 
 struct WideParams {
     const u16 *x;      // [32 MG, K] bf16 activations (rows beyond the real ones are padding: finite, results dropped)
@@ -123,12 +123,16 @@ __device__ __forceinline__ void wide_store(u16 *out, int ld_out, int n32, int to
     }
 }
 
-template <int MG>
-__global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
+// MG token groups of 32; WV waves per workgroup (4: 128 rows of W per workgroup, 2: 64 rows -- twice the workgroups for
+// the same N, at twice the activation bytes per byte of weight); WKS k-steps of 16 per LDS chunk (8 with 4 waves, 4 with 2:
+// a thread stages MG * WKS / WV = 8 pieces of a 128-row chunk either way)
+template <int MG, int WV, int WKS>
+__global__ __launch_bounds__(64 * WV) void wide_gemm_kernel(WideParams p) {
+    constexpr int WIDE_KS = WKS, WIDE_BK = 16 * WKS, WIDE_THREADS = 64 * WV;   // (shadow the 4-wave constants)
     __shared__ bf16x8 xs[2][WIDE_KS][MG][64];   // B fragments of a chunk: lane l = token (l & 31), k = 8 (l >> 5) + e
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n32 = (int)blockIdx.x * 4 + w;           // this wave's 32 weight rows
+    const int n32 = (int)blockIdx.x * WV + w;          // this wave's 32 weight rows
     const int split = blockIdx.y;
     const int chunks = p.K / WIDE_BK;
     const int c0 = (int)((long long)chunks * split / p.splitk), c1 = (int)((long long)chunks * (split + 1) / p.splitk);
@@ -140,12 +144,13 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
     // a token (one phase of a ds_write_b128) would otherwise all fall on the same four banks (their addresses differ by
     // multiples of 512 bytes): a 16-way conflict, 1.7 us of LDS time per chunk against 0.43 us of MFMAs.  The readers
     // apply the same XOR (a permutation inside each 16-lane phase: their reads stay conflict-free).
-    constexpr int PIECES = MG * 32 * 16 / WIDE_THREADS;   // per thread: 4 (64 rows) or 8 (128 rows)
+    constexpr int PPR = 2 * WIDE_KS;                              // 16-byte pieces per token row and chunk
+    constexpr int PIECES = MG * 32 * PPR / WIDE_THREADS;          // per thread: 4 (64 rows) or 8 (128 rows)
     const u16 *xsrc[PIECES];
     bf16x8 *xdst[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const int q = tid + WIDE_THREADS * i, token = q >> 4, piece = q & 15;
+        const int q = tid + WIDE_THREADS * i, token = q / PPR, piece = q % PPR;
         xsrc[i] = p.x + (size_t)token * p.K + piece * 8;
         xdst[i] = &xs[0][piece >> 1][token >> 5][(32 * (piece & 1) + (token & 31)) ^ ((piece >> 1) | ((piece & 1) << 3))];
     }
@@ -168,11 +173,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_gemm_kernel(WideParams p) {
         // UNCONDITIONAL -- past the end a chunk re-loads the last one, an L2 hit nobody uses -- and the counts are the
         // same in every iteration.  Program order of the loads of chunk c: NX activation pieces for chunk c + 2, then
         // one weight fragment for chunk c + 2 behind each k-step's MFMAs.  Hence, in steady state and from the prologue
-        // on:  * the weight fragment of k-step s was requested 2 chunks ago; behind it came 7 - s + (NX + 8) + NX + s
-        //        loads: vmcnt(15 + 2 NX) in front of every k-step;
+        // on (KS k-steps per chunk):
+        //      * the weight fragment of k-step s was requested 2 chunks ago; behind it came KS - 1 - s + (NX + KS) + NX + s
+        //        loads: vmcnt(2 KS - 1 + 2 NX) in front of every k-step;
         //      * the pieces staged at the end of chunk c (for chunk c + 1) were requested at the top of chunk c - 1;
-        //        behind them came 8 + NX + 8 loads: vmcnt(16 + NX).
-        constexpr int NX = PIECES, W_WAIT = 15 + 2 * NX, X_WAIT = 16 + NX;
+        //        behind them came KS + NX + KS loads: vmcnt(2 KS + NX).
+        constexpr int NX = PIECES, W_WAIT = 2 * WIDE_KS - 1 + 2 * NX, X_WAIT = 2 * WIDE_KS + NX;
         const int clast = c1 - 1;
         auto gload = [](bf16x8 &dst, const void *ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory"); };
         auto gload_nt = [](bf16x8 &dst, const void *ptr) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr) : "memory"); };
@@ -282,6 +288,25 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_reduce_kernel(WideReducePar
     wide_store(p.out, p.ld_out, n32, token, h, sum, p.epilogue);
 }
 
+// 128-row tiles (4 waves) unless they give the chip fewer than 100 workgroups: then 64-row tiles (2 waves, twice the
+// workgroups at twice the activation bytes per byte of weight).  Measured (profiles/r04_wide_gemm.txt): down at 64 rows,
+// splitk 4: 24.1 us with 80 workgroups of 128 rows, 18.9 with 160 of 64; gate|up unsplit: 29.0 us with 152 workgroups of
+// 128 rows, 41.5 with 304 of 64.
+void wide_launch(const WideParams &p, int m_pad, int n, hipStream_t st) {
+    const int wg128 = (n / 128) * p.splitk;
+    int tile = wg128 >= 100 ? 128 : 64;
+    if (const char *v = getenv("CRAG_WIDE_TILE")) tile = atoi(v) == 64 ? 64 : 128;   // (developer switch)
+    if (tile == 128) {
+        const dim3 grid((unsigned)(n / 128), (unsigned)p.splitk);
+        if (m_pad == 64) hipLaunchKernelGGL((wide_gemm_kernel<2, 4, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wide_gemm_kernel<4, 4, 8>), grid, dim3(256), 0, st, p);
+    } else {
+        const dim3 grid((unsigned)(n / 64), (unsigned)p.splitk);
+        if (m_pad == 64) hipLaunchKernelGGL((wide_gemm_kernel<2, 2, 4>), grid, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((wide_gemm_kernel<4, 2, 4>), grid, dim3(128), 0, st, p);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -298,6 +323,7 @@ int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, in
     if (n <= 0 || n % 128) return wfail("wide_gemm: n must be a multiple of 128 (got %d)", n);
     if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm: k must be a multiple of %d (got %d)", WIDE_BK, k);
     if (splitk <= 0 || splitk > k / WIDE_BK) return wfail("wide_gemm: splitk must be in [1, k / %d] (got %d)", WIDE_BK, splitk);
+    if (n % 64) return wfail("wide_gemm: n must be a multiple of 64");
     WideParams p;
     p.x = x;
     p.ww = ww;
@@ -307,9 +333,7 @@ int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, in
     p.K = k;
     p.n32 = n / 32;
     p.splitk = splitk;
-    const dim3 grid((unsigned)(n / 128), (unsigned)splitk);
-    if (m_pad == 64) hipLaunchKernelGGL(wide_gemm_kernel<2>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wide_gemm_kernel<4>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    wide_launch(p, m_pad, n, (hipStream_t)stream);
     return whip_ok("wide_gemm");
 }
 
@@ -332,9 +356,7 @@ int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *o
     p.K = k;
     p.n32 = n / 32;
     p.splitk = 1;
-    const dim3 grid((unsigned)(n / 128), 1u);
-    if (m_pad == 64) hipLaunchKernelGGL(wide_gemm_kernel<2>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wide_gemm_kernel<4>, grid, dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    wide_launch(p, m_pad, n, (hipStream_t)stream);
     return whip_ok("wide_gemm_direct");
 }
 

@@ -257,8 +257,8 @@ class Qwen3Encoder:
         """gate|up and down a second time in the fragment order crag_enc_wide_gemm streams (+ 5.4 GB for the 4B model),
         for forwards of exactly 64 or 128 token rows (3 to 8 queries of <= 16 tokens: the gateway's batch sizes,
         RUNBOOK:304,331-334).  Those are the projections where the weight-streaming kernel beats the library's small-M
-        GEMM (profiles/r04_wide_gemm.txt, per layer at 128 rows: gate|up + SwiGLU 30.2 vs 38.9 us in ONE launch, down 24.3
-        vs 39.4; at 64 rows gate|up 23.9 vs 31.6); qkv and o stay with the library.  None when the widths are not the 4B
+        GEMM (profiles/r04_wide_gemm.txt, per layer at 128 rows: gate|up + SwiGLU 29.0 vs 37.2 us in ONE launch, down 24.1
+        vs 39.3; at 64 rows gate|up 23.5 vs 30.9, down 18.9 vs 21.7); qkv and o stay with the library.  None when the widths are not the 4B
         model's, CRAG_ENC_NO_WIDE is set or the copies do not fit."""
         c = self.cfg
         off = os.environ.get("CRAG_ENC_NO_WIDE") is not None or self.__dict__.get("_wide_failed", False)
@@ -405,9 +405,9 @@ class Qwen3Encoder:
             else:
                 gate_up = F.linear(normed, L["gate_up"])
                 ops.swiglu(gate_up, act)
-            if wide is not None and t == 128:   # ... and down with K split 8 ways (at 64 rows the library's GEMM is level)
+            if wide is not None:   # ... and down with K split 8 ways (128 rows) / 4 ways (64 rows, 64-row tiles)
                 delta = ops.wide_gemm(act, wide[i]["down"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
-                                      c.hidden_size, 8)
+                                      c.hidden_size, 8 if t == 128 else 4)
             else:
                 delta = F.linear(act, L["down"])
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
@@ -479,6 +479,17 @@ class Qwen3Encoder:
     @torch.no_grad()
     def _forward_small(self, token_lists: Sequence[Sequence[int]], lens: Sequence[int], bucket: int) -> torch.Tensor:
         n = len(lens)
+        # 33..63 / 97..127 padded rows: phantom sequences round the batch up to 64 / 128 rows, where gate|up and down are
+        # the weight-streaming kernels (3 queries of 16 tokens: 3.66 ms through the library's GEMMs at 48 rows, 3.49 ms as
+        # 64 rows; 7 queries 4.48 -> 4.22 ms; at 80 / 96 rows the library's 4.0 ms beat the 128-row path's 4.24) -- their
+        # outputs are dropped below
+        n_real = n
+        if bucket <= 64 and (32 < n * bucket < 64 or 96 < n * bucket < 128) and self._wide_weights() is not None:
+            target = 64 if n * bucket < 64 else 128
+            if target % bucket == 0:
+                n = target // bucket
+                token_lists = list(token_lists) + [[0]] * (n - n_real)
+                lens = list(lens) + [1] * (n - n_real)
         if n * bucket in (64, 128):
             self._wide_weights()        # (a flip of CRAG_ENC_NO_WIDE drops the graphs captured over the other kernels)
         if n * bucket in (16, 32):
@@ -494,7 +505,7 @@ class Qwen3Encoder:
         g["last_tok"].copy_(g["h_last"], non_blocking=True)
         g["uploaded"].record()
         g["graph"].replay()
-        return g["out"].clone()
+        return g["out"][:n_real].clone()
 
     @torch.no_grad()
     def embed_token_lists(self, token_lists: Sequence[Sequence[int]]) -> torch.Tensor:

@@ -13,7 +13,7 @@ def lat(fn, n=30):
     for _ in range(n):
         fn(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
-for nq in (1, 2, 3, 4, 8, 64):
+for nq in (1, 2, 3, 4, 5, 6, 7, 8, 64):
     toks = [rng.integers(0, cfg.vocab_size, size=16).tolist() for _ in range(nq)]
     row = f"nq {nq:2d} x 16 tokens:"
     for wide in (True, False):

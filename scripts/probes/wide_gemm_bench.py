@@ -9,7 +9,7 @@ from cadence_rag_amd.encoder import ops
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 shapes = [("qkv", 6144, 2560, False), ("o", 2560, 4096, False), ("gate_up", 19456, 2560, True), ("down", 2560, 9728, False)]
-splits = {"qkv": (1, 2, 4, 5, 10), "o": (4, 8, 16), "gate_up": (1, 2, 4), "down": (4, 8, 19, 38)}
+splits = {"qkv": (1, 2, 4), "o": (2, 4, 8), "gate_up": (1, 2), "down": (2, 4, 8, 19)}
 COPIES, CALLS = 4, 16
 def graph_time(fn):
     s = torch.cuda.Stream()
@@ -44,12 +44,15 @@ for m in (128, 64):
             lib_us = graph_time(lambda i: torch.matmul(x, ws[i % COPIES].t(), out=lin))
         line = f"m {m} {name:8s} [{n} x {k}] {n*k*2/1e6:6.1f} MB: library{' + swiglu' if swi else ''} {lib_us:6.1f} us ({n*k*2/lib_us/1e6:5.2f} TB/s)"
         best = 1e9
-        for sk in splits[name]:
-            ops.wide_gemm(x, wws[0], out, m, n, sk, swiglu=swi, scratch=scratch)
-            err = float((out.float() - ref).abs().max()); scale = float(ref.abs().max())
-            us = graph_time(lambda i: ops.wide_gemm(x, wws[i % COPIES], out, m, n, sk, swiglu=swi, scratch=scratch))
-            best = min(best, us)
-            line += f" | splitk {sk}: {us:6.1f} us ({n*k*2/us/1e6:5.2f} TB/s) err {err/scale:.1e}"
+        for tile in ("128", "64"):
+            os.environ["CRAG_WIDE_TILE"] = tile     # (developer switch: rows of W per workgroup; default: by workgroup count)
+            for sk in splits[name]:
+                ops.wide_gemm(x, wws[0], out, m, n, sk, swiglu=swi, scratch=scratch)
+                err = float((out.float() - ref).abs().max()); scale = float(ref.abs().max())
+                us = graph_time(lambda i: ops.wide_gemm(x, wws[i % COPIES], out, m, n, sk, swiglu=swi, scratch=scratch))
+                best = min(best, us)
+                line += f" | tile {tile} splitk {sk}: {us:5.1f} us err {err/scale:.0e}"
+        os.environ.pop("CRAG_WIDE_TILE", None)
         tot_lib += lib_us; tot_best += best
         print(line, flush=True)
         del ws, wws
