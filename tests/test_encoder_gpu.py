@@ -628,7 +628,8 @@ def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, spl
         assert torch.allclose(got, want.float().cpu(), atol=3e-3, rtol=3e-2), (got - want.float().cpu()).abs().max()
 
 
-@pytest.mark.parametrize("lens", [[16, 3, 9, 16, 1, 12, 7, 15], [16, 2, 11, 5], [40], [100], [30, 32, 17, 9]])
+@pytest.mark.parametrize("lens", [[16, 3, 9, 16, 1, 12, 7, 15], [16, 2, 11, 5], [40], [100], [30, 32, 17, 9],
+                                  [16, 5, 9], [16, 3, 9, 16, 1, 12, 7]])   # (the last two: rounded up with phantom sequences)
 def test_three_to_eight_short_queries_use_the_wide_projections_and_match_transformers(gpu, monkeypatch, lens):
     """The gateway's batch sizes (max_batch_size 8, preferred 1 / 2 / 4 / 8, RUNBOOK:304,331-334): 3 to 8 queries of
     <= 16 tokens, or one query of 33 to 128 tokens = one graph replay over 64 or 128 token rows, whose gate|up + SwiGLU
