@@ -83,7 +83,7 @@ def search_leg(index, queries, k, steps, warmup, rounds, step_extra=None, fence_
     """Warm up, then time `rounds` x `steps` searches of `queries` (device tensor) on torch's current stream.
     Returns timing + live HIP-event kernel times + the prefilter path's candidate statistics.
     pipelined: the steps go through crag_index_search_pipelined (the throughput form for a run of independent
-    searches from one stream: consecutive searches alternate between two streams of the index's own) with ONE
+    searches from one stream: consecutive searches rotate over three streams of the index's own) with ONE
     crag_index_join in front of every fence -- the queries are resident and the outputs are read behind the fence."""
     dev = queries.device
     nq = int(queries.shape[0])
@@ -711,7 +711,7 @@ def main() -> None:
                          "one crag_index_join per fence).  The other form is timed beside it.")
     ap.add_argument("--no-other-api", action="store_true",
                     help="skip the leg that times the other form of the API (profiling runs: its launches of the same "
-                         "kernel overlap on two streams and would be averaged into the rocprofv3 duration)")
+                         "kernel overlap across streams and would be averaged into the rocprofv3 duration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-encode", action="store_true", help="skip the chunks-embedded/sec leg")
     ap.add_argument("--no-target-1m", action="store_true", help="skip the 1M x 1024 single-GPU leg (N = 1 only)")
@@ -800,7 +800,7 @@ def main() -> None:
             dist.barrier()
 
     # N = 1: the timed steps are a run of independent searches over resident queries -> the library's throughput form
-    # (crag_index_search_pipelined: consecutive searches alternate between two streams of the index's own, one join in
+    # (crag_index_search_pipelined: consecutive searches rotate over three streams of the index's own, one join in
     # front of every fence).  The in-order form (crag_index_search_async, one stream) is timed beside it.  N > 1: a
     # step's collective consumes the search's output on the stream -> in order.
     pipelined = world == 1 and args.api == "pipelined"

@@ -187,8 +187,8 @@ class DenseIndex:
     def search_pipelined(self, d_queries, k: int, d_out_ids, d_out_scores, d_out_counts,
                          d_row_mask=None, mask_stride: int = 0, stream: int = 0, inputs_ready: bool = False) -> None:
         """Throughput form for a run of INDEPENDENT searches issued from one stream (crag_index_search_pipelined):
-        consecutive calls alternate between two streams of the index's own, so search i + 1's preparation and scan run
-        beside search i's selection.  The outputs are defined on `stream` only behind join(stream).  inputs_ready: the
+        consecutive calls rotate over three streams of the index's own (k <= 24; larger k runs in order), so search
+        i + 1's preparation and scan run beside search i's selection.  The outputs are defined on `stream` only behind join(stream).  inputs_ready: the
         queries / mask are complete in memory now (no event orders the internal stream behind `stream`)."""
         nq = int(d_queries.shape[0])
         _native.check(self._lib.crag_index_search_pipelined(

@@ -685,7 +685,7 @@ def test_concurrent_host_threads_and_streams(gpu):
 
 
 def test_pipelined_searches_from_one_stream_equal_the_in_order_form(gpu):
-    """crag_index_search_pipelined: a run of independent searches issued from ONE stream alternates between two
+    """crag_index_search_pipelined: a run of independent searches issued from ONE stream rotates over the
     streams of the index's own (search i + 1's preparation and scan beside search i's selection); outputs are defined
     behind crag_index_join.  Same bits as crag_index_search_async, for mixed batch sizes and k (fp32 path, prefilter
     path, shared selection), with the inputs produced on the caller's stream right before the call (the fork event
