@@ -458,7 +458,10 @@ int crag_enc_small_gemm(const uint16_t *x, const uint16_t *delta, const uint16_t
     } else if (k == 4096 && !pro && epilogue == 0 && rows_per_tile == 10) {
         if (mg == 1) CRAG_SMALL(1, 16, 8, 16, 10, 0, 0, 0, 1); else CRAG_SMALL(2, 16, 8, 16, 10, 0, 0, 0, 1);
     } else if (k == 9728 && !pro && epilogue == 0 && rows_per_tile == 10) {
-        if (mg == 1) CRAG_SMALL(1, 38, 8, 12, 10, 0, 0, 0, 1); else CRAG_SMALL(2, 38, 8, 12, 10, 0, 0, 0, 2);
+        // 16 rows: ring depth 19 = half of a wave's 38 k-steps (2.528 -> 2.477 ms per one-query forward against depth
+        // 12; depth 16: 2.523; the whole tile up front with the activations in two passes: 2.510 --
+        // profiles/r04_nq1_variants.txt; there too: both qkv tiles of a workgroup up front, no gain)
+        if (mg == 1) CRAG_SMALL(1, 38, 8, 19, 10, 0, 0, 0, 1); else CRAG_SMALL(2, 38, 8, 12, 10, 0, 0, 0, 2);
     } else {
         return efail("small_gemm: unsupported form k=%d rows_per_tile=%d epilogue=%d prologue=%d (built for the "
                      "Qwen3-Embedding-4B widths: k 2560 with the RMSNorm prologue and 12 / 16-row tiles, k 4096 and "

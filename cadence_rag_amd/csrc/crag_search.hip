@@ -2130,7 +2130,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             }
         }
         if (ti == der_base + PF_DERIVE_LAG) der_base = pf_next_pub(der_base, c.n_tiles, PF_READ_LAG);
-        {   // emergency derivations asked for on the previous tile (see below): wave w takes the flagged queries = w mod 8
+        if constexpr (MIRROR) {   // emergency derivations asked for on the previous tile (see below): wave w takes the
+                                  // flagged queries = w mod 8.  (fp32 rows: the block costs the scan's registers 8-22 spilled
+                                  // dwords and 12 % of its rate at 100 000 rows; there a scan overlapped with another
+                                  // search's kernels may end in the overflow fallback -- slower, same results.)
             uint32_t need[NQB];
 #pragma unroll
             for (int i = 0; i < NQB; ++i) need[i] = __builtin_amdgcn_readfirstlane((int)L.need[i]);
@@ -2160,7 +2163,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             // in the overflow fallback (measured: two scans of 1M rows started together, 1.9 ms per search instead of
             // 0.33).  So the wave asks ITS OWN workgroup for an emergency derivation (L.need: one bit per query of the
             // pass; the waves share the flagged queries on the next tile, below) and reads again on the tile after.
-            if (any_without_bound()) {
+            if (MIRROR && any_without_bound()) {
                 if (j == 0) {
 #pragma unroll
                     for (int e = 0; e < RPO; ++e)
