@@ -75,6 +75,8 @@ SIGNATURES = {
     "crag_enc_wide_reduce": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "crag_enc_small_attention": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                             _c.c_float, _P]),
+    "crag_enc_small_attention_seqs": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int,
+                                                 _c.c_int, _c.c_float, _c.c_float, _P]),
 }
 
 

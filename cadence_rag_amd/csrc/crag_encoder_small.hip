@@ -269,6 +269,7 @@ struct SmallAttnParams {
     const float *cos_sin;  // [max_pos, 64, 2], or (cs_by_token) [T, 64, 2]: the rows of the tokens' positions
     const int32_t *positions;
     u16 *out;  // [T, hq * 128]
+    const int32_t *cu;  // NULL: ONE block of n_tokens rows; else [gridDim.y + 1]: block y = rows cu[y] .. cu[y + 1] - 1 (one sequence)
     int n_tokens, hq, hkv, cs_by_token;
     float eps, scale_log2;
 };
@@ -290,6 +291,8 @@ __global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p)
     const int kvh = h / (p.hq / p.hkv);
     const int64_t row_stride = (int64_t)(p.hq + 2 * p.hkv) * CRAG_HEAD_DIM;
     const int grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int tok0 = p.cu ? p.cu[blockIdx.y] : 0;
+    const int ntok = p.cu ? min(p.cu[blockIdx.y + 1] - tok0, T) : p.n_tokens;
 
     Pack8s raw[ITEMS];
     float cs[ITEMS][16];
@@ -299,11 +302,11 @@ __global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p)
         const int head = which == 0 ? h : (which == 1 ? p.hq + kvh : p.hq + p.hkv + kvh);
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[i].v[e] = 0;
-        if (t < p.n_tokens) {
-            raw[i] = *reinterpret_cast<const Pack8s *>(p.qkv + t * row_stride + (int64_t)head * CRAG_HEAD_DIM + sub * 8);
+        if (t < ntok) {
+            raw[i] = *reinterpret_cast<const Pack8s *>(p.qkv + (tok0 + t) * row_stride + (int64_t)head * CRAG_HEAD_DIM + sub * 8);
             if (which != 2) {
                 // a table gathered per token (once per forward) takes a dependent load out of every layer's chain
-                const float *src = p.cos_sin + ((int64_t)(p.cs_by_token ? t : p.positions[t]) * 64 + (sub & 7) * 8) * 2;
+                const float *src = p.cos_sin + ((int64_t)(p.cs_by_token ? tok0 + t : p.positions[tok0 + t]) * 64 + (sub & 7) * 8) * 2;
 #pragma unroll
                 for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4 *>(&cs[i][e]) = *reinterpret_cast<const float4 *>(src + e);
             }
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p)
     const Pack8s wk8 = *reinterpret_cast<const Pack8s *>(p.kw + sub * 8);
     for (int i = threadIdx.x; i < CRAG_HEAD_DIM * 40 / 2; i += THREADS) reinterpret_cast<uint32_t *>(&Vt[0][0])[i] = 0;
     if (threadIdx.x < T)
-        start[threadIdx.x] = (int)threadIdx.x < p.n_tokens ? (int)threadIdx.x - p.positions[threadIdx.x] : -1 - (int)threadIdx.x;
+        start[threadIdx.x] = (int)threadIdx.x < ntok ? (int)threadIdx.x - p.positions[tok0 + threadIdx.x] : -1 - (int)threadIdx.x;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p)
             const float partner = __shfl_xor(n, 8);
             const float rot = sub < 8 ? -partner : partner;
             const float cv = bf2f(f2bf(cs[i][2 * e])), sn = bf2f(f2bf(cs[i][2 * e + 1]));  // the model casts cos/sin to bf16
-            o8.v[e] = t < p.n_tokens ? f2bf(n * cv + rot * sn) : (u16)0;
+            o8.v[e] = t < ntok ? f2bf(n * cv + rot * sn) : (u16)0;
         }
         *reinterpret_cast<Pack8s *>(which == 0 ? &Qs[t][sub * 8] : &Ks[t][sub * 8]) = o8;
     }
@@ -400,8 +403,8 @@ __global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p)
         const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&Vt[16 * nt + c][8 * g]);
         const f32x4_t o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pv, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         // O^T[d = 16 nt + 4 g + r][query c]
-        if (qtok < p.n_tokens)
-            *reinterpret_cast<uint2 *>(p.out + (size_t)qtok * p.hq * CRAG_HEAD_DIM + (size_t)h * CRAG_HEAD_DIM + 16 * nt + 4 * g) =
+        if (qtok < ntok)
+            *reinterpret_cast<uint2 *>(p.out + (size_t)(tok0 + qtok) * p.hq * CRAG_HEAD_DIM + (size_t)h * CRAG_HEAD_DIM + 16 * nt + 4 * g) =
                 make_uint2((uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16), (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16));
     }
 }
@@ -487,12 +490,42 @@ int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, cons
     p.n_tokens = n_tokens;
     p.hq = hq;
     p.hkv = hkv;
+    p.cu = nullptr;
     p.cs_by_token = cos_sin_by_token != 0;
     p.eps = eps;
     p.scale_log2 = scale * 1.4426950408889634f;
     if (n_tokens <= 16) hipLaunchKernelGGL(small_attn_kernel<1>, dim3((unsigned)hq), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(small_attn_kernel<2>, dim3((unsigned)hq), dim3(512), 0, (hipStream_t)stream, p);
     return hip_ok("small_attention");
+}
+
+int crag_enc_small_attention_seqs(const uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w,
+                                  const float *cos_sin, int cos_sin_by_token, const int32_t *positions,
+                                  const int32_t *cu_seqlens, int n_seqs, int max_len, uint16_t *out, int hq, int hkv,
+                                  float eps, float scale, void *stream) {
+    if (!qkv || !q_norm_w || !k_norm_w || !cos_sin || !positions || !cu_seqlens || !out)
+        return efail("small_attention_seqs: NULL pointer");
+    if (n_seqs <= 0 || n_seqs > 65535) return efail("small_attention_seqs: 1..65535 sequences (got %d)", n_seqs);
+    if (max_len <= 0 || max_len > 32) return efail("small_attention_seqs: sequences of 1..32 tokens (max_len %d)", max_len);
+    if (hq <= 0 || hkv <= 0 || hq % hkv) return efail("small_attention_seqs: hq must be a multiple of hkv");
+    SmallAttnParams p;
+    p.qkv = qkv;
+    p.qw = q_norm_w;
+    p.kw = k_norm_w;
+    p.cos_sin = cos_sin;
+    p.positions = positions;
+    p.out = out;
+    p.cu = cu_seqlens;
+    p.n_tokens = 0;
+    p.hq = hq;
+    p.hkv = hkv;
+    p.cs_by_token = cos_sin_by_token != 0;
+    p.eps = eps;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    const dim3 grid((unsigned)hq, (unsigned)n_seqs);
+    if (max_len <= 16) hipLaunchKernelGGL(small_attn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(small_attn_kernel<2>, grid, dim3(512), 0, (hipStream_t)stream, p);
+    return hip_ok("small_attention_seqs");
 }
 
 }  // extern "C"

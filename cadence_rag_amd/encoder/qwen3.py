@@ -82,6 +82,7 @@ class PackedBatch:
     blk_q0: torch.Tensor      # int32 [n_blocks]
     last_tok: torch.Tensor    # int64 [B]: packed position of every sequence's last token
     cu_one: torch.Tensor      # int32 [B+1] = 0..B: the batch of last tokens as B one-token sequences
+    max_len: int = 0          # longest sequence (host side: picks the attention kernel)
 
     @staticmethod
     def build(lengths: Sequence[int], device) -> "PackedBatch":
@@ -109,7 +110,8 @@ class PackedBatch:
 
         last_tok = torch.from_numpy(np.ascontiguousarray(cu[1:] - 1)).to(device, non_blocking=True)
         return PackedBatch(t, int(lens.size), t_pad, dev(cu), dev(cu_pad), dev(positions), dev(tok_of_pad),
-                           dev(blk_seq[order]), dev(blk_q0[order]), last_tok, dev(np.arange(lens.size + 1)))
+                           dev(blk_seq[order]), dev(blk_q0[order]), last_tok, dev(np.arange(lens.size + 1)),
+                           int(lens.max()))
 
 
 QKV_ROW_CHUNK = 32768
@@ -357,6 +359,9 @@ class Qwen3Encoder:
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
         wide = self._wide_weights() if t in (64, 128) else None
+        short_seqs = (0 < batch.max_len <= 32 and batch.n_seqs <= 65535 and skinny is None
+                      and os.environ.get("CRAG_ENC_NO_SHORT_ATTN") is None)
+        cs_tok = self._cos_sin.index_select(0, batch.positions.long()) if short_seqs else None   # once per forward
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -371,10 +376,17 @@ class Qwen3Encoder:
             for lo in range(0, t if skinny is None else 0, QKV_ROW_CHUNK):
                 hi = min(t, lo + QKV_ROW_CHUNK)
                 torch.matmul(normed[lo:hi], L["qkv"].t(), out=qkv[lo:hi])
-            ops.qk_rope_vt(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
-                           c.num_heads, c.num_kv_heads, c.rms_norm_eps, vt, batch.tok_of_pad)
-            ops.attention(qkv_buf, vt, attn, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0,
-                          c.num_heads, c.num_kv_heads, scale)
+            if short_seqs:
+                # every sequence <= 32 tokens (a batch of short queries): q/k-norm + RoPE + attention in ONE launch, a
+                # workgroup per (q head, sequence), instead of the rope / V-transpose launch + the flash kernel
+                ops.small_attention_seqs(qkv, L["q_norm"], L["k_norm"], cs_tok, batch.positions, batch.cu, batch.n_seqs,
+                                         batch.max_len, attn, c.num_heads, c.num_kv_heads, c.rms_norm_eps, scale,
+                                         by_token=True)
+            else:
+                ops.qk_rope_vt(qkv_buf, L["q_norm"], L["k_norm"], self._cos_sin, batch.positions,
+                               c.num_heads, c.num_kv_heads, c.rms_norm_eps, vt, batch.tok_of_pad)
+                ops.attention(qkv_buf, vt, attn, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0,
+                              c.num_heads, c.num_kv_heads, scale)
             if last_only and i == len(self.layers) - 1:
                 # Last layer, last-token pooling: behind the attention only the B pooled rows matter (no later
                 # layer reads the other tokens' hidden states), so the output projection, the second norm and the

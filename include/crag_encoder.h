@@ -120,6 +120,14 @@ int crag_enc_small_gemm(const uint16_t *x, const uint16_t *delta, const uint16_t
 int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w,
                              const float *cos_sin, int cos_sin_by_token, const int32_t *positions, uint16_t *out,
                              int n_tokens, int hq, int hkv, float eps, float scale, void *stream);
+/* The same kernel over a packed batch of n_seqs SHORT sequences (every one <= max_len <= 32 tokens; cu_seqlens[n_seqs + 1]
+ * = their first rows, as crag_enc_attention takes it): one workgroup per (q head, sequence), grid (hq, n_seqs) -- q/k-norm
+ * + RoPE + attention of a batch of short queries (3 to 8 of them: the gateway's batch sizes) in ONE launch instead of
+ * crag_enc_qk_rope_vt + crag_enc_attention.  positions[T], cos_sin as above; qkv is not modified. */
+int crag_enc_small_attention_seqs(const uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w,
+                                  const float *cos_sin, int cos_sin_by_token, const int32_t *positions,
+                                  const int32_t *cu_seqlens, int n_seqs, int max_len, uint16_t *out, int hq, int hkv,
+                                  float eps, float scale, void *stream);
 
 /* ---- the linear layers at 64 / 128 token rows: what the gateway's batcher hands the model (RUNBOOK:304,331-334:
  * max_batch_size 8, preferred_batch_size [1, 2, 4, 8]) -- csrc/crag_encoder_wide.hip ----

@@ -598,6 +598,62 @@ def test_small_attention_fuses_qk_norm_rope_and_causal_attention(gpu, lens):
     assert torch.allclose(got, old.float().cpu().view(t, hq, 128), atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("lens", [[16] * 8, [16, 3, 9, 16, 1, 12, 7, 15], [32, 17, 5, 32], [1], [9, 32], [2] * 70])
+def test_small_attention_over_a_packed_batch_of_short_sequences(gpu, lens):
+    """crag_enc_small_attention_seqs: one workgroup per (q head, sequence) over a packed batch whose sequences all have
+    <= 32 tokens (ragged starts: the blocks follow cu_seqlens) -- against the fp32 reference, against the two launches
+    it replaces (crag_enc_qk_rope_vt + crag_enc_attention), and bit for bit against crag_enc_small_attention run on each
+    sequence by itself (the same kernel, one block)."""
+    from cadence_rag_amd.encoder import ops
+    from cadence_rag_amd.encoder.qwen3 import PackedBatch, Qwen3Config, Qwen3Encoder
+    hq, hkv = 32, 8
+    g = torch.Generator().manual_seed(sum(lens) * 7 + len(lens))
+    t = sum(lens)
+    qkv = _bf(torch.randn(t + 32, (hq + 2 * hkv) * 128, generator=g))
+    qw, kw = _bf(1 + 0.1 * torch.randn(128, generator=g)), _bf(1 + 0.1 * torch.randn(128, generator=g))
+    cfg = Qwen3Config(max_length=64)
+    table = Qwen3Encoder._rope_table(cfg).to(DEV)
+    batch = PackedBatch.build(lens, DEV)
+    assert batch.max_len == max(lens)
+    before = qkv.clone()
+    out = torch.full((t + 1, hq * 128), 9.0, dtype=BF, device=DEV)
+    cs_tok = table.index_select(0, batch.positions.long())
+    ops.small_attention_seqs(qkv[:t], qw, kw, cs_tok, batch.positions, batch.cu, len(lens), batch.max_len, out[:t], hq, hkv,
+                             1e-6, 1 / math.sqrt(128), by_token=True)
+    assert torch.equal(qkv, before) and torch.all(out[t] == 9.0)
+    full_table = torch.full_like(out, 7.0)                        # the whole table + positions: same bits
+    ops.small_attention_seqs(qkv[:t], qw, kw, table, batch.positions, batch.cu, len(lens), batch.max_len, full_table[:t],
+                             hq, hkv, 1e-6, 1 / math.sqrt(128))
+    assert torch.equal(full_table[:t], out[:t])
+    got = out[:t].float().cpu().view(t, hq, 128)
+    assert torch.isfinite(got).all()
+    pos = batch.positions.cpu()
+
+    def normed(block, w, heads):
+        v = block.float().cpu().view(t, heads, 128)
+        return _rope_ref(v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float().cpu(), pos, cfg.rope_theta)
+
+    ref = _attn_ref(normed(before[:t, : hq * 128], qw, hq), normed(before[:t, hq * 128: (hq + hkv) * 128], kw, hkv),
+                    before[:t, (hq + hkv) * 128:].float().cpu().view(t, hkv, 128), lens, hq, hkv)
+    assert torch.allclose(got, ref, atol=3e-2, rtol=3e-2), (lens, (got - ref).abs().max())
+    vt = torch.empty(hkv, 128, batch.t_pad, dtype=BF, device=DEV)
+    work = qkv.clone()
+    ops.qk_rope_vt(work, qw, kw, table, batch.positions, hq, hkv, 1e-6, vt, batch.tok_of_pad)
+    old = torch.empty(t, hq * 128, dtype=BF, device=DEV)
+    ops.attention(work, vt, old, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
+    assert torch.allclose(got, old.float().cpu().view(t, hq, 128), atol=2e-2, rtol=2e-2)
+    # each sequence by itself through the one-block entry point (the block size is picked per call there: compare the
+    # sequences whose own length picks the same kernel as the batch's longest)
+    lo = 0
+    for n in lens[:6]:
+        if (n <= 16) == (batch.max_len <= 16):
+            one = torch.empty(n, hq * 128, dtype=BF, device=DEV)
+            ops.small_attention(qkv[lo:lo + n], qw, kw, table, batch.positions[lo:lo + n].contiguous(), one, hq, hkv, 1e-6,
+                                1 / math.sqrt(128))
+            assert torch.equal(one, out[lo:lo + n]), (lens, lo)
+        lo += n
+
+
 @pytest.mark.parametrize("k,n,swiglu,splitk", [(2560, 6144, False, 4), (4096, 2560, False, 8), (9728, 2560, False, 8),
                                               (9728, 2560, False, 1), (2560, 19456, True, 1), (2560, 19456, True, 3)])
 @pytest.mark.parametrize("m_rows,m_pad", [(128, 128), (97, 128), (64, 64), (33, 64)])
