@@ -1,6 +1,7 @@
 // crag_encoder_small.hip — the Qwen3-Embedding decoder layer at the reference's own operating point: ONE short
 // query per /retrieve request (/root/reference/app/retrieve.py:427 embeds one string), i.e. 16 or 32 token rows.
-// C ABI: include/crag_encoder.h (crag_enc_small_gemm, crag_enc_small_attention).
+// C ABI: include/crag_encoder.h (crag_enc_small_gemm, crag_enc_small_attention; crag_enc_small_attention_seqs runs the
+// attention kernel over a packed batch of short sequences, one workgroup per (q head, sequence)).
 //
 // At that size a layer is a WEIGHT STREAM: 202 MB of bf16 weights against 16 rows of activations, 25 us at
 // 8 TB/s.  Round 3's first version ran a layer as eight launches (two RMSNorms, q/k-norm + RoPE + V transpose,

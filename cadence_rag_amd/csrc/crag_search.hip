@@ -2163,13 +2163,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void prefilter_kernel(PfParams p) {
             // in the overflow fallback (measured: two scans of 1M rows started together, 1.9 ms per search instead of
             // 0.33).  So the wave asks ITS OWN workgroup for an emergency derivation (L.need: one bit per query of the
             // pass; the waves share the flagged queries on the next tile, below) and reads again on the tile after.
-            if (MIRROR && any_without_bound()) {
-                if (j == 0) {
+            if (any_without_bound()) {
+                if constexpr (MIRROR) {
+                    if (j == 0) {
 #pragma unroll
-                    for (int e = 0; e < RPO; ++e)
-                        if (((o.okmask >> e) & 1u) && tau[e] == 0u) atomicOr(&L.need[(o.ql0 + e) >> 5], 1u << ((o.ql0 + e) & 31));
+                        for (int e = 0; e < RPO; ++e)
+                            if (((o.okmask >> e) & 1u) && tau[e] == 0u) atomicOr(&L.need[(o.ql0 + e) >> 5], 1u << ((o.ql0 + e) & 31));
+                    }
                 }
-                next_read = ti + 1;
+                next_read = ti + 1;   // (fp32-row kernels: no emergency derivation, but still no tile without asking again)
             } else {
                 rd_base = pf_next_pub(rd_base, c.n_tiles, PF_READ_LAG);
                 while (rd_base + PF_READ_LAG <= ti) rd_base = pf_next_pub(rd_base, c.n_tiles, PF_READ_LAG);  // (terminates: rd_base grows)
