@@ -28,7 +28,8 @@ for rows in (100_000, 1_000_000):
             prev = row[0]
             for i, nm in enumerate(names):
                 x = row[i + 1]
-                if x:
+                if x and x >= prev:       # (a mark older than the block's start is left over from an earlier search:
+                                          # only the block that arrives last gathers)
                     txt.append(f"{nm} {(x - prev) / 100:.2f}")
                     prev = x
             print(f"  block {r}: " + ", ".join(txt) + f"  | total {(prev - row[0]) / 100:.2f} us, C={row[8]}, rescored={row[9]}")
