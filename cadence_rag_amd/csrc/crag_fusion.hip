@@ -37,6 +37,18 @@ struct FuseParams {
 // then takes the order-preserving quadratic path (round 2's only path: 61 us for 64 queries x 200 ids, all of them).
 constexpr int FUSE_SLOTS = 2048;  // >= 2 * FUSE_MAX_ITEMS
 
+// (developer build, -DCRAG_FUSE_TRACE: query 0's workgroup stamps the 100 MHz clock at its phase boundaries;
+// scripts/probes/fuse_phase_trace.py)
+#ifdef CRAG_FUSE_TRACE
+__device__ unsigned long long g_fuse_trace[16];
+#define FUSE_T(i)                                                                   \
+    do {                                                                            \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_fuse_trace[i] = wall_clock64();  \
+    } while (0)
+#else
+#define FUSE_T(i) ((void)0)
+#endif
+
 __device__ __forceinline__ uint32_t fuse_hash(int64_t k) {
     uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> 40);
@@ -44,7 +56,7 @@ __device__ __forceinline__ uint32_t fuse_hash(int64_t k) {
 
 __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
     __shared__ int64_t key[FUSE_MAX_ITEMS];
-    __shared__ double term[FUSE_MAX_ITEMS];   // 1 / (k + rank) of the item
+    __shared__ alignas(16) double term[FUSE_MAX_ITEMS + 4];   // 1 / (k + rank) of the item; afterwards: the ranking keys
     __shared__ double score[FUSE_MAX_ITEMS];  // valid at first-occurrence positions
     __shared__ uint32_t lanes[FUSE_MAX_ITEMS];
     __shared__ uint8_t lane_of[FUSE_MAX_ITEMS];
@@ -56,6 +68,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
     __shared__ int s_dup, s_unique;
     const int q = blockIdx.x, tid = threadIdx.x;
     constexpr unsigned long long EMPTY = 0x8000000000000001ull;  // (not a valid id: ids are >= -1)
+    FUSE_T(0);
     if (tid == 0) {
         int o = 0;
         for (int l = 0; l < p.n_lanes; ++l) {
@@ -74,6 +87,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
         slot_lanes[i] = 0u;
     }
     __syncthreads();
+    FUSE_T(1);
     const int total = offs[p.n_lanes];
     for (int l = 0; l < p.n_lanes; ++l) {
         const int cnt = offs[l + 1] - offs[l];
@@ -104,6 +118,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
         }
     }
     __syncthreads();
+    FUSE_T(2);
     if (s_dup == 0) {
         // slot -> position of the key's first item; scores live at those positions
         for (int i = tid; i < total; i += FUSE_THREADS) {
@@ -146,15 +161,33 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
         }
         __syncthreads();
     }
+    FUSE_T(3);
+    // rank = number of keys with a higher score, or the same score and an earlier first occurrence (the stable sort).
+    // The scores are positive doubles, so their bit patterns order like the values: the ranking keys are the bit
+    // patterns at first-occurrence positions and 0 everywhere else (never above, never equal), padded to a
+    // multiple of 4 -- the loop reads four keys per step as two 16-byte broadcasts and compares integers.
+    // (Round 3's loop read first[jj] and score[jj] per key and compared doubles: 19 of the kernel's 23 us.)
+    unsigned long long *sb = reinterpret_cast<unsigned long long *>(term);
+    const int total4 = (total + 3) & ~3;
+    for (int i = tid; i < total4; i += FUSE_THREADS)
+        sb[i] = (i < total && first[i] == i) ? (unsigned long long)__double_as_longlong(score[i]) : 0ull;
+    __syncthreads();
     int mine_unique = 0;
     for (int i = tid; i < total; i += FUSE_THREADS) {
         if (first[i] != i) continue;
         ++mine_unique;
         const double s = score[i];
+        const unsigned long long sv = sb[i];
         int rank = 0;
-#pragma unroll 8
-        for (int jj = 0; jj < total; ++jj)
-            rank += (first[jj] == jj && (score[jj] > s || (score[jj] == s && jj < i))) ? 1 : 0;
+#pragma unroll 2
+        for (int jj = 0; jj < total4; jj += 4) {
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&sb[jj]);
+            const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(&sb[jj + 2]);
+            rank += (a.x > sv || (a.x == sv && jj < i)) ? 1 : 0;
+            rank += (a.y > sv || (a.y == sv && jj + 1 < i)) ? 1 : 0;
+            rank += (b.x > sv || (b.x == sv && jj + 2 < i)) ? 1 : 0;
+            rank += (b.y > sv || (b.y == sv && jj + 3 < i)) ? 1 : 0;
+        }
         if (rank < p.out_k) {
             p.out_ids[(size_t)q * p.out_k + rank] = key[i];
             p.out_scores[(size_t)q * p.out_k + rank] = s;
@@ -163,6 +196,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
     }
     if (mine_unique) atomicAdd(&s_unique, mine_unique);
     __syncthreads();
+    FUSE_T(4);
     const int cnt = s_unique < p.out_k ? s_unique : p.out_k;
     if (tid == 0) p.out_counts[q] = cnt;
     for (int r = cnt + tid; r < p.out_k; r += FUSE_THREADS) {
@@ -170,6 +204,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void rrf_fuse_kernel(FuseParams p) {
         p.out_scores[(size_t)q * p.out_k + r] = __longlong_as_double(0x7ff8000000000000ll);
         p.out_lanes[(size_t)q * p.out_k + r] = 0u;
     }
+    FUSE_T(5);
 }
 
 int ffail(const char *msg) {
@@ -178,6 +213,12 @@ int ffail(const char *msg) {
 }
 
 }  // namespace
+
+#ifdef CRAG_FUSE_TRACE
+extern "C" int crag_fuse_trace_read(unsigned long long *host16) {
+    return hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_fuse_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int crag_rrf_fuse(int n_lanes, const int64_t *const *d_lane_ids, const int32_t *const *d_lane_counts,
                              const int *lane_width, int nq, int rrf_k, int out_k, int64_t *d_out_ids,
