@@ -805,12 +805,10 @@ int crag_index_search_pipelined(crag_index *ix, const float *d_queries, int nq, 
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(ix->mu);
     DeviceGuard guard(ix->device);
-    if (!ix->pipe[0]) {
-        for (int i = 0; i < ix->n_pipe; ++i) {
-            HIP_TRY(hipStreamCreateWithFlags(&ix->pipe[i], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ix->pipe_fork[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ix->pipe_done[i], hipEventDisableTiming));
-        }
+    for (int i = 0; i < ix->n_pipe; ++i) {   // created on first use; a creation that failed is tried again, not skipped
+        if (!ix->pipe[i]) HIP_TRY(hipStreamCreateWithFlags(&ix->pipe[i], hipStreamNonBlocking));
+        if (!ix->pipe_fork[i]) HIP_TRY(hipEventCreateWithFlags(&ix->pipe_fork[i], hipEventDisableTiming));
+        if (!ix->pipe_done[i]) HIP_TRY(hipEventCreateWithFlags(&ix->pipe_done[i], hipEventDisableTiming));
     }
     // Overlap pays for the searches whose small kernels are a large share of the step -- k <= 24 (one class set): 100 000
     // x 64, k = 10: 40.2 us per step on three streams against 47.7 in order; 1M: 316 against 322 -- and costs for larger k,

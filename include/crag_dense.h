@@ -69,7 +69,8 @@ int crag_index_destroy(crag_index *ix);
  * Replaces: _update_embeddings' per-row UPDATE (embedding_pipeline.py:157-168).
  * Appending is safe while searches enqueued earlier with crag_index_search_async are still running (they
  * never read past the size they were launched with); crag_index_update rewrites rows in place and must
- * not overlap in time with searches in flight on other streams. */
+ * not overlap in time with searches in flight on other streams -- those of crag_index_search_pipelined run on
+ * streams of the index's own: crag_index_join + a synchronisation of the joined stream come first. */
 int crag_index_add(crag_index *ix, const float *rows, const int64_t *ids, int64_t n);
 
 /* Overwrite the vectors of rows [pos, pos+n) (positions, not ids) — re-embed in place. */
