@@ -41,6 +41,10 @@ SIGNATURES = {
     "crag_merge_topk_packed": (_c.c_int, [_c.c_int, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P]),
     "crag_rrf_fuse": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _P, _P]),
     "crag_tech_lane": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int64, _P, _P, _P, _P]),
+    "crag_upload_slot_create": (_P, []),
+    "crag_upload_slot_destroy": (None, [_P]),
+    "crag_tech_lane_host": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int64, _P, _P, _P,
+                                       _P, _P]),
     "crag_index_profile_enable": (_c.c_int, [_P, _c.c_int]),
     "crag_index_profile_read": (_c.c_int, [_P, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double),
                                            _c.POINTER(_c.c_double)]),

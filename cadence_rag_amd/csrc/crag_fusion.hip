@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
+#include <new>
 
 #include "../../include/crag_dense.h"
 
@@ -451,4 +453,95 @@ extern "C" int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, 
         return CRAG_EHIP;
     }
     return CRAG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The lane from HOST token hashes: the upload slot (pinned host buffer + its device twin + the event of the last
+// copy that read the host buffer) lives here, so that a call is: wait for the slot, pack, ONE async copy, two
+// launches -- no tensor library in between (the Python path spent 65 us per call around 20 us of kernels).
+// ------------------------------------------------------------------------------------------------
+struct crag_upload_slot {
+    void *host = nullptr;   // pinned: [64][32] uint64 query tokens, then [64] int32 counts
+    void *dev = nullptr;
+    hipEvent_t copied = nullptr;
+    bool pending = false;
+    int device = 0;
+};
+namespace {
+constexpr size_t SLOT_QT_BYTES = (size_t)TECH_MAX_Q * 32 * sizeof(uint64_t);
+constexpr size_t SLOT_BYTES = SLOT_QT_BYTES + (size_t)TECH_MAX_Q * sizeof(int32_t);
+}  // namespace
+
+extern "C" crag_upload_slot *crag_upload_slot_create(void) {
+    crag_upload_slot *s = new (std::nothrow) crag_upload_slot();
+    if (!s) {
+        crag_set_error_("upload_slot: out of host memory");
+        return nullptr;
+    }
+    if (hipGetDevice(&s->device) != hipSuccess || hipHostMalloc(&s->host, SLOT_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(&s->dev, SLOT_BYTES) != hipSuccess ||
+        hipEventCreateWithFlags(&s->copied, hipEventDisableTiming) != hipSuccess) {
+        crag_set_error_("upload_slot: allocation failed");
+        if (s->host) (void)hipHostFree(s->host);
+        if (s->dev) (void)hipFree(s->dev);
+        delete s;
+        return nullptr;
+    }
+    memset(s->host, 0, SLOT_BYTES);
+    return s;
+}
+
+extern "C" void crag_upload_slot_destroy(crag_upload_slot *s) {
+    if (!s) return;
+    if (s->pending) (void)hipEventSynchronize(s->copied);
+    (void)hipEventDestroy(s->copied);
+    (void)hipHostFree(s->host);
+    (void)hipFree(s->dev);
+    delete s;
+}
+
+extern "C" int crag_tech_lane_host(const int32_t *d_order, const int64_t *d_row_ptr, const uint64_t *d_tokens,
+                                   const int64_t *d_ids, int64_t n_rows, const uint64_t *h_token_hashes,
+                                   const int32_t *h_token_counts, int nq, int k, const uint8_t *d_row_mask,
+                                   int64_t mask_stride, crag_upload_slot *slot, uint64_t *d_bitmap_scratch,
+                                   int64_t *d_out_ids, int32_t *d_out_counts, void *stream) {
+    if (!slot || !h_token_counts || (!h_token_hashes && nq > 0)) return ffail("tech_lane_host: NULL pointer");
+    if (nq < 0 || nq > TECH_MAX_Q) return ffail("tech_lane_host: need 0 <= nq <= 64");
+    if (nq == 0) return CRAG_OK;
+    if (slot->pending) {   // the copy that last read the pinned buffer has left it
+        if (hipEventSynchronize(slot->copied) != hipSuccess) return ffail("tech_lane_host: waiting for the upload slot failed");
+        slot->pending = false;
+    }
+    uint64_t *qt = (uint64_t *)slot->host;
+    int32_t *qn = (int32_t *)((char *)slot->host + SLOT_QT_BYTES);
+    const uint64_t *src = h_token_hashes;
+    for (int q = 0; q < nq; ++q) {   // distinct hashes, first occurrence kept (the SQL `&&` is a set overlap)
+        const int n = h_token_counts[q];
+        if (n < 0) return ffail("tech_lane_host: negative token count");
+        uint64_t *row = qt + (size_t)q * 32;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const uint64_t h = src[i];
+            bool seen = false;
+            for (int j = 0; j < m; ++j) seen = seen || row[j] == h;
+            if (seen) continue;
+            if (m == 32) {
+                crag_set_error_("tech_lane_host: more than 32 distinct tokens in a query (the caller splits it into passes)");
+                return CRAG_E2BIG;
+            }
+            row[m++] = h;
+        }
+        qn[q] = m;
+        src += n;
+    }
+    if (hipMemcpyAsync(slot->dev, slot->host, SLOT_QT_BYTES + (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice,
+                       (hipStream_t)stream) != hipSuccess ||
+        hipEventRecord(slot->copied, (hipStream_t)stream) != hipSuccess) {
+        crag_set_error_("tech_lane_host: upload failed");
+        return CRAG_EHIP;
+    }
+    slot->pending = true;
+    return crag_tech_lane(d_order, d_row_ptr, d_tokens, d_ids, n_rows, (const uint64_t *)slot->dev,
+                          (const int32_t *)((const char *)slot->dev + SLOT_QT_BYTES), nq, k, d_row_mask, mask_stride,
+                          d_bitmap_scratch, d_out_ids, d_out_counts, stream);
 }

@@ -61,6 +61,7 @@ def rrf_fuse(lanes: Sequence[Tuple[torch.Tensor, torch.Tensor]], out_k: int, rrf
 # ------------------------------------------------------------------------------------------------
 import hashlib  # noqa: E402
 from array import array  # noqa: E402
+from itertools import chain  # noqa: E402
 
 import numpy as np  # noqa: E402
 
@@ -72,6 +73,7 @@ def token_hash(token: str) -> int:
     return int.from_bytes(hashlib.blake2b(token.encode("utf-8"), digest_size=8).digest(), "little")
 
 
+_ONE_ZERO = array("Q", [0])
 _HASH_CACHE_MAX = 1 << 18
 _hash_cache: dict = {}   # token string -> hash.  Query tokens repeat (ticket ids, error names, versions): a lookup is
                          # ~30 ns, blake2b + int.from_bytes ~1 us.  Dropped wholesale when it reaches the cap.
@@ -80,8 +82,8 @@ _hash_cache: dict = {}   # token string -> hash.  Query tokens repeat (ticket id
 def _hashes(token_lists) -> "array":
     """All tokens of all lists, hashed, flat, in list order (array('Q'))."""
     cache = _hash_cache
-    try:
-        return array("Q", [cache[t] for toks in token_lists for t in toks])
+    try:   # (flattening and looking up without a Python-level loop: half the time of the comprehension)
+        return array("Q", list(map(cache.__getitem__, chain.from_iterable(token_lists))))
     except KeyError:
         if len(cache) > _HASH_CACHE_MAX:
             cache.clear()
@@ -116,7 +118,6 @@ class TechTokenIndex:
         self.row_ptr = torch.from_numpy(row_ptr).to(device)
         self.tokens = torch.from_numpy(toks.view(np.int64)).to(device)
         self.ids = torch.from_numpy(ids).to(device)
-        self._arange = np.arange(64 * MAX_QUERY_TOKENS)
         self._bitmaps: dict = {}   # per stream: two streams sharing one index must not share scratch
         self._pinned: dict = {}    # per stream: ring of pinned upload buffers for the query tokens
         self._rank_of_id = None
@@ -124,69 +125,79 @@ class TechTokenIndex:
         self._row_tokens = [frozenset(t) for t in row_tokens] if verify else None
         self._pos_of_id = None
 
-    _QT_BYTES = 64 * MAX_QUERY_TOKENS * 8   # the query-token block of an upload slot; the 64 counts (int32) follow
-
     def _slot(self, stream: int):
-        """Next upload slot of the stream's ring of four: ONE pinned host buffer (query-token hashes [64, 32] int64 |
-        token counts [64] int32), its device twin, the per-k output tensors and the event of the slot's last upload.
-        Everything is allocated once per stream: a call allocates nothing and uploads with ONE copy.  [Round 3: four
-        torch.empty on the device per call, two copies, blake2b per token: 156 us of host time around 22 us of
-        kernels.]"""
+        """Next upload slot of the stream's ring of four: a crag_upload_slot of the library (pinned host buffer for the
+        query-token hashes [64, 32] + counts [64], its device twin, the event of its last upload) and the per-k output
+        tensors.  Everything is allocated once per stream: a call allocates nothing and uploads with ONE copy.
+        [Round 3: four torch.empty on the device per call, two copies, blake2b per token: 156 us of host time around
+        22 us of kernels; round 4 first: a pinned torch buffer packed with numpy, 65 us; the packing, the copy and the
+        event now live behind crag_tech_lane_host.]"""
         ring = self._pinned.setdefault(stream, {"next": 0, "slots": []})
         if len(ring["slots"]) < 4:
-            nbytes = self._QT_BYTES + 64 * 4
-            host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-            hnp = host.numpy()
-            ring["slots"].append({
-                "host": host, "dev": torch.empty(nbytes, dtype=torch.uint8, device=self.device),
-                "h_qt": hnp[:self._QT_BYTES].view(np.uint64).reshape(64, MAX_QUERY_TOKENS),
-                "h_qn": hnp[self._QT_BYTES:].view(np.int32), "done": torch.cuda.Event(), "out": {}})
+            with torch.cuda.device(self.device):
+                handle = _native.load().crag_upload_slot_create()
+            if not handle:
+                raise _native.NativeLibraryError(f"crag_upload_slot_create failed: {_native.last_error()}")
+            ring["slots"].append({"handle": handle, "out": {}})
         slot = ring["slots"][ring["next"] % len(ring["slots"])]
         ring["next"] += 1
         return slot
 
-    def _pass(self, token_lists, k: int, row_mask, mask_stride: int, stream: int):
-        """One launch of the lane: at most MAX_QUERY_TOKENS tokens per query.  The returned tensors belong to the
-        stream's upload ring: they are valid until the fourth following call on the same stream."""
+    def close(self) -> None:
+        """Free the upload slots (pinned host memory).  Called by __del__ as well."""
+        rings, self._pinned = getattr(self, "_pinned", {}), {}
+        for ring in rings.values():
+            for slot in ring["slots"]:
+                _native.load().crag_upload_slot_destroy(slot["handle"])
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the library may be gone already
+            pass
+
+    _E2BIG = -4   # crag_dense.h CRAG_E2BIG: a query with more than 32 distinct tokens, nothing was enqueued
+
+    def _pass(self, token_lists, k: int, row_mask, mask_stride: int, stream: int, borrow: bool = True):
+        """One launch of the lane (crag_tech_lane_host: the hashes are packed, uploaded and matched behind ONE call).
+        borrow: the returned tensors belong to the stream's upload ring and are valid until the fourth following call
+        on the same stream; otherwise they are fresh.  Returns None when a query holds more than MAX_QUERY_TOKENS
+        DISTINCT tokens (nothing was enqueued: the caller splits it into passes)."""
         nq = len(token_lists)
         if nq > 64:
             raise ValueError("the exact-token lane takes at most 64 queries per call")
-        lens = list(map(len, token_lists))
         flat = _hashes(token_lists)
+        lens = array("i", map(len, token_lists))
+        if not len(flat):
+            flat = _ONE_ZERO                     # (a valid address; no query reads it: all counts are 0)
         words = max((self.n + 63) // 64, 1)
-        with _on_stream(stream, self.device):
-            # uploads from a small ring of pinned buffers: a copy from pageable memory blocks the host until the
-            # stream has reached it, i.e. until the dense scan enqueued in front of it has finished -- host and GPU
-            # in lockstep, one step at a time
-            slot = self._slot(stream)
-            slot["done"].synchronize()          # the copy that last used this slot has left the host buffer
-            h_qt, h_qn = slot["h_qt"], slot["h_qn"]
-            h_qn[:nq] = lens
-            if len(flat):                       # (only the first lens[q] tokens of a query are ever read)
-                fa = np.frombuffer(flat, dtype=np.uint64)
-                if lens.count(lens[0]) == nq:
-                    h_qt[:nq, :lens[0]] = fa.reshape(nq, lens[0])
-                else:
-                    la = h_qn[:nq]
-                    ar = self._arange
-                    h_qt[np.repeat(ar[:nq], la), ar[:len(flat)] - np.repeat(np.cumsum(la) - la, la)] = fa
-            slot["dev"].copy_(slot["host"], non_blocking=True)
-            slot["done"].record()
-            d_base = slot["dev"].data_ptr()
-            bitmap = self._bitmaps.get(stream)
-            if bitmap is None or bitmap.numel() < nq * words:
-                bitmap = self._bitmaps[stream] = torch.empty(nq * words, dtype=torch.int64, device=self.device)
+        slot = self._slot(stream)
+        bitmap = self._bitmaps.get(stream)
+        if bitmap is None or bitmap.numel() < nq * words:
+            with _on_stream(stream, self.device):
+                bitmap = self._bitmaps[stream] = torch.empty(64 * words, dtype=torch.int64, device=self.device)
+        if borrow:
             outs = slot["out"].get(k)
             if outs is None:
-                outs = slot["out"][k] = (torch.empty(64, k, dtype=torch.int64, device=self.device),
-                                         torch.empty(64, dtype=torch.int32, device=self.device))
+                with _on_stream(stream, self.device):
+                    outs = slot["out"][k] = (torch.empty(64, k, dtype=torch.int64, device=self.device),
+                                             torch.empty(64, dtype=torch.int32, device=self.device))
             out_ids, out_ct = outs[0][:nq], outs[1][:nq]
-            lib = _native.load()
-            _native.check(lib.crag_tech_lane(self.order.data_ptr(), self.row_ptr.data_ptr(), self.tokens.data_ptr(),
-                                             self.ids.data_ptr(), self.n, d_base, d_base + self._QT_BYTES, nq,
-                                             int(k), None if row_mask is None else row_mask.data_ptr(),
-                                             int(mask_stride), bitmap.data_ptr(), out_ids.data_ptr(),
-                                             out_ct.data_ptr(), ctypes.c_void_p(stream)), "crag_tech_lane")
+        else:   # fresh outputs: ONE allocation, the counts behind the ids
+            with _on_stream(stream, self.device):
+                block = torch.empty(nq * k + (nq + 1) // 2, dtype=torch.int64, device=self.device)
+            out_ids, out_ct = block[:nq * k].view(nq, k), block[nq * k:].view(torch.int32)[:nq]
+        ptrs = self.__dict__.get("_ptrs")
+        if ptrs is None:
+            ptrs = self._ptrs = (self.order.data_ptr(), self.row_ptr.data_ptr(), self.tokens.data_ptr(), self.ids.data_ptr())
+        rc = _native.load().crag_tech_lane_host(ptrs[0], ptrs[1], ptrs[2], ptrs[3], self.n, flat.buffer_info()[0],
+                                                lens.buffer_info()[0], nq, int(k),
+                                                None if row_mask is None else row_mask.data_ptr(), int(mask_stride),
+                                                slot["handle"], bitmap.data_ptr(), out_ids.data_ptr(), out_ct.data_ptr(),
+                                                ctypes.c_void_p(stream))
+        if rc == self._E2BIG:
+            return None
+        _native.check(rc, "crag_tech_lane_host")
         return out_ids, out_ct
 
     def search(self, query_token_lists, k: int, row_mask=None, mask_stride: int = 0, stream: int = 0,
@@ -203,17 +214,18 @@ class TechTokenIndex:
         what a caller that consumes them at once wants -- HybridSearcher feeds them to the fusion kernel); the
         default returns copies.
         Returns (ids int64 [nq, k] -1 padded, counts int32 [nq]) CUDA tensors, best (most recent) first."""
-        lists = [list(dict.fromkeys(toks)) for toks in query_token_lists]  # distinct, first occurrence kept
         check = (self._row_tokens is not None) if verify is None else (bool(verify) and self._row_tokens is not None)
+        if not check:
+            # the common, stream-ordered path: the library drops repeated tokens itself and says so when a query
+            # needs more than one pass
+            fast = self._pass(query_token_lists, k, row_mask, mask_stride, stream, borrow)
+            if fast is not None:
+                return fast
+        lists = [list(dict.fromkeys(toks)) for toks in query_token_lists]  # distinct, first occurrence kept
         passes = max(1, max((-(-len(t) // MAX_QUERY_TOKENS) for t in lists), default=1))
         if passes == 1:
-            out_ids, out_ct = self._pass(lists, k, row_mask, mask_stride, stream)
-            if check:
-                out_ids, out_ct = self._verified(lists, k, out_ids, out_ct, row_mask, mask_stride, stream)
-            if not borrow:
-                with _on_stream(stream, self.device):
-                    out_ids, out_ct = out_ids.clone(), out_ct.clone()
-            return out_ids, out_ct
+            out_ids, out_ct = self._pass(lists, k, row_mask, mask_stride, stream, borrow)
+            return self._verified(lists, k, out_ids, out_ct, row_mask, mask_stride, stream) if check else (out_ids, out_ct)
         if self._rank_of_id is None:
             order = self.order.cpu().numpy()
             ids = self.ids.cpu().numpy()

@@ -33,6 +33,7 @@ extern "C" {
 #define CRAG_EINVAL (-1)   /* bad argument */
 #define CRAG_EHIP (-2)     /* HIP runtime error (message has hipGetErrorString) */
 #define CRAG_ENOMEM (-3)   /* capacity exceeded / allocation failed */
+#define CRAG_E2BIG (-4)    /* an input exceeds what one call takes; the caller splits it (crag_tech_lane_host) */
 #define CRAG_ENODEV (-4)   /* no usable gfx950 device */
 
 #define CRAG_MAX_K 128     /* reference uses k = 50 / 10 (retrieve.py:18-19); BASELINE asks 10..100 */
@@ -175,6 +176,22 @@ int crag_tech_lane(const int32_t *d_order, const int64_t *d_row_ptr, const uint6
                    const int32_t *d_query_token_counts, int nq, int k, const uint8_t *d_row_mask,
                    int64_t mask_stride, uint64_t *d_bitmap_scratch, int64_t *d_out_ids,
                    int32_t *d_out_counts, void *stream);
+
+/* The same lane for a caller that holds the query tokens on the HOST (the gateway does: extract_tech_tokens runs there).
+ * An upload slot = a pinned host buffer, its device twin and the event of the last copy that read the host buffer; a
+ * caller keeps a small ring of them per stream (the call waits for the slot's previous copy only).  The call packs the
+ * hashes (duplicates inside a query dropped, first occurrence kept), enqueues ONE host-to-device copy and the two
+ * kernels on `stream` and returns.
+ *   h_token_hashes  host: the queries' token hashes back to back;  h_token_counts host [nq]: tokens per query
+ *   CRAG_E2BIG: a query holds more than 32 DISTINCT tokens -- nothing was enqueued, the caller runs it in passes. */
+typedef struct crag_upload_slot crag_upload_slot;
+crag_upload_slot *crag_upload_slot_create(void);
+void crag_upload_slot_destroy(crag_upload_slot *slot);
+int crag_tech_lane_host(const int32_t *d_order, const int64_t *d_row_ptr, const uint64_t *d_tokens,
+                        const int64_t *d_ids, int64_t n_rows, const uint64_t *h_token_hashes,
+                        const int32_t *h_token_counts, int nq, int k, const uint8_t *d_row_mask, int64_t mask_stride,
+                        crag_upload_slot *slot, uint64_t *d_bitmap_scratch, int64_t *d_out_ids, int32_t *d_out_counts,
+                        void *stream);
 
 /* Live kernel timing for bench.py's roofline: enabled = N > 0 records HIP events around the scan
  * (and merge) kernel of every N-th search, on the stream it is launched on (N = 1: every search;

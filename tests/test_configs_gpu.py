@@ -396,6 +396,54 @@ def test_tech_lane_with_more_than_32_query_tokens(gpu):
         assert got_ids[qi, :int(got_ct[qi])].tolist() == want
 
 
+def test_tech_lane_from_host_hashes_in_one_call(gpu):
+    """verify=False (the stream-ordered path HybridSearcher takes): crag_tech_lane_host packs the hashes in the library's
+    own upload slots -- repeated tokens inside a query dropped there, 32 distinct tokens + repeats still one pass, a
+    query with more distinct tokens falls back to passes, empty lists, a row mask, ten calls in a row over the ring of
+    four slots with different queries, borrowed and fresh outputs."""
+    import torch
+    from cadence_rag_amd.fusion import TechTokenIndex
+    rng = np.random.default_rng(31)
+    n = 6000
+    vocab = [f"T-{i}" for i in range(300)]
+    row_tokens = [list(rng.choice(vocab, size=rng.integers(0, 3), replace=False)) for _ in range(n)]
+    ids = np.arange(n, dtype=np.int64) * 2 + 11
+    started = np.datetime64("2026-03-01", "us") + rng.integers(0, 30, size=n).astype("timedelta64[D]")
+    dev = torch.device("cuda", 0)
+    tech = TechTokenIndex(row_tokens, ids, started, dev, verify=False)
+    order = np.lexsort((ids, -started.astype(np.int64)))
+    elig = rng.random(n) < 0.6
+    mask = torch.from_numpy(DenseIndex.pack_mask(elig)).to(dev)
+
+    def want(toks, k, use_mask):
+        return [int(ids[p]) for p in order if set(row_tokens[p]) & set(toks) and (elig[p] or not use_mask)][:k]
+
+    def check(queries, k, use_mask, borrow):
+        got_ids, got_ct = tech.search(queries, k, row_mask=mask if use_mask else None, verify=False, borrow=borrow)
+        torch.cuda.synchronize()
+        gi, gc = got_ids.cpu().numpy(), got_ct.cpu().numpy()
+        assert gi.shape == (len(queries), k)
+        for qi, toks in enumerate(queries):
+            w = want(toks, k, use_mask)
+            assert int(gc[qi]) == len(w) and gi[qi, :len(w)].tolist() == w and np.all(gi[qi, len(w):] == -1), qi
+
+    full = list(rng.choice(vocab, size=32, replace=False))
+    one_pass = [full + full[:9], [], ["T-5", "T-5", "T-5"], ["not-a-token"], list(rng.choice(vocab, size=3, replace=False))]
+    for borrow in (False, True):
+        for use_mask in (False, True):
+            check(one_pass, 20, use_mask, borrow)
+    check([list(rng.choice(vocab, size=33, replace=False)), ["T-1"]], 20, False, False)     # 33 distinct: passes
+    for i in range(10):                                           # the ring of four slots, a different batch every call
+        check([list(rng.choice(vocab, size=int(m), replace=True)) for m in rng.integers(0, 12, size=1 + i % 7)], 7, i % 2 == 1,
+              True)
+    a = tech.search(one_pass, 20, verify=False)                   # fresh outputs survive later calls
+    for _ in range(6):
+        tech.search([["T-9"]], 20, verify=False, borrow=True)
+    torch.cuda.synchronize()
+    assert a[0][0, :int(a[1][0])].tolist() == want(one_pass[0], 20, False)
+    tech.close()
+
+
 def test_tech_lane_hash_collisions_are_repaired_from_the_strings(gpu, monkeypatch):
     """The kernel matches 64-bit token hashes; TechTokenIndex (verify=True, the default) checks every returned row
     against the token STRINGS and re-evaluates a query on a mismatch, so the lane has the SQL `&&` semantics
