@@ -91,7 +91,7 @@ struct crag_index {
     int64_t *ids = nullptr;
     // search workspaces are per stream (up to MAX_WS streams): searches enqueued on different streams
     // may overlap on the GPU, same-stream searches are ordered by the stream itself
-    static constexpr int MAX_WS = 4;
+    static constexpr int MAX_WS = 8;   // (= crag::PF_STAT_WS; buffers are allocated on a workspace's first search)
     struct Workspace {
         hipStream_t stream = nullptr;
         bool in_use = false;
@@ -100,7 +100,7 @@ struct crag_index {
         DevBuf a32, a16, qinv, pf_gbound, pf_cand, pf_count, pf_flags, pf_xkeys, pf_xids, pf_xcount, pf_xticket;
         hipEvent_t done = nullptr;   // created with the index, recorded after every search that used this workspace
         uint32_t seq = 0;            // sequence number of the last prefilter search on this workspace (never 0 in use)
-        bool done_recorded = false;  // ... once a second stream has appeared (single-stream callers pay no event)
+        bool done_recorded = false;  // ... once every workspace has an owner (until then nobody can take one over)
         // a search failed between its scan launch and its selection launch: the per-query state the selection kernel
         // leaves zeroed (class maxima, candidate counts, tickets) may hold the failed search's values -- the next search
         // on this workspace re-zeroes it first
@@ -115,7 +115,7 @@ struct crag_index {
     bool pipe_pending[MAX_PIPE] = {false, false, false, false};
     unsigned pipe_next = 0;
     uint64_t use_clock = 0;
-    bool multi_stream = false;  // more than one stream has searched this index
+    bool record_done = false;   // every workspace has an owner: from now on a search records its workspace's event
     int64_t last_id = INT64_MIN;  // largest id stored so far (ids are strictly ascending with the row position)
     // developer switches, read from the environment once, when the index is created
     bool env_no_wide = false, env_no_reverse = false, env_unpipelined = false, env_no_prefilter = false, env_no_rsplit = false;
@@ -139,6 +139,8 @@ struct crag_index {
     std::vector<EvSet> ev_pool;
     size_t ev_used = 0;
 };
+
+static_assert(crag_index::MAX_WS == crag::PF_STAT_WS, "one block of statistics records per workspace");
 
 namespace {
 
@@ -184,11 +186,13 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
     if (!ws)
         for (auto &w : ix->ws)
             if (!w.in_use) {
-                // a second stream: from now on every search records its workspace's completion event
-                if (&w != &ix->ws[0]) ix->multi_stream = true;
                 w.in_use = true;
                 w.stream = st;
                 ws = &w;
+                // the last free workspace: the next new stream takes one over, so from now on every search records
+                // its workspace's completion event (until then: no event packet per search -- it cost a step 4-7 us
+                // for every caller with two to four streams, and for crag_index_search_pipelined)
+                if (&w == &ix->ws[crag_index::MAX_WS - 1]) ix->record_done = true;
                 break;
             }
     if (!ws) {
@@ -199,9 +203,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         if (ws->done_recorded && !ws->dirty) {   // (a failed search recorded no event)
             HIP_TRY(hipStreamWaitEvent(st, ws->done, 0));
         } else {
-            // its last search predates the second stream (no event was recorded then): wait for the device
+            // its last search predates the moment the workspaces ran out (no event was recorded then): wait for the device
             HIP_TRY(hipDeviceSynchronize());
         }
+        ix->record_done = true;
         ws->stream = st;
     }
     ws->last_use = ++ix->use_clock;
@@ -433,11 +438,10 @@ int search_device(crag_index *ix, const float *d_queries, int nq, int k, const u
         HIP_TRY(crag::launch_merge_partials(mp, nq, st));
     }
     if (ev) HIP_TRY(hipEventRecord(ev->e3, st));
-    // what a stream that later takes this workspace over waits for.  Recorded only once a second stream has used the
-    // index: a single-stream caller (the common case) pays no event packet per search, and a workspace can be taken
-    // over only when MAX_WS other streams exist.
-    ws->done_recorded = ix->multi_stream;
-    if (ix->multi_stream) HIP_TRY(hipEventRecord(ws->done, st));
+    // what a stream that later takes this workspace over waits for.  Recorded only once every workspace has an owner:
+    // callers with up to MAX_WS streams (the pipelined form's three included) pay no event packet per search.
+    ws->done_recorded = ix->record_done;
+    if (ix->record_done) HIP_TRY(hipEventRecord(ws->done, st));
     return CRAG_OK;
 }
 
@@ -825,8 +829,7 @@ int crag_index_search_pipelined(crag_index *ix, const float *d_queries, int nq, 
     rc = search_device(ix, d_queries, nq, k, d_row_mask, mask_stride, d_out_ids, d_out_scores, d_out_counts,
                        ix->pipe[i]);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ix->pipe_done[i], ix->pipe[i]));
-    ix->pipe_pending[i] = true;
+    ix->pipe_pending[i] = true;   // (its completion event is recorded by the join: one per fence and stream, not per search)
     return CRAG_OK;
 }
 
@@ -836,6 +839,7 @@ int crag_index_join(crag_index *ix, void *stream) {
     DeviceGuard guard(ix->device);
     for (int i = 0; i < ix->n_pipe; ++i)
         if (ix->pipe_pending[i]) {
+            HIP_TRY(hipEventRecord(ix->pipe_done[i], ix->pipe[i]));
             HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, ix->pipe_done[i], 0));
             ix->pipe_pending[i] = false;
         }

@@ -56,7 +56,8 @@ struct MergeParams {
 // per-query bound record: 128 class maxima (4 sets x 32 row classes), padded to five 128-byte lines so that the
 // records of two queries never share a line
 constexpr int PF_BOUND_CELLS = 160;
-constexpr int PF_STAT_SLOTS = 1024;           // per-query statistics records (summed on the host when read)
+constexpr int PF_STAT_WS = 8;                 // search workspaces per index (crag_api.hip MAX_WS): a block of records each
+constexpr int PF_STAT_SLOTS = 2048;           // per-query statistics records (summed on the host when read)
 constexpr int PF_MIN_ROWS_PER_GROUP = 128;    // below this many rows per workgroup the plain fp32 scan is used
 
 struct PrepParams {
@@ -104,7 +105,7 @@ struct FinParams {
     int64_t *out_ids;
     float *out_scores;
     int32_t *out_counts;
-    unsigned long long *stats;  // nullable; the workspace's PF_STAT_SLOTS / 4 records {candidates, rescored rows, searches}
+    unsigned long long *stats;  // nullable; the workspace's PF_STAT_SLOTS / PF_STAT_WS records {candidates, rescored rows, searches}
     int k, cap;
     int nq;                     // selection blocks of the launch: [0, nq * rsplit)
     int rsplit;                 // selection blocks per query (R)

@@ -2422,10 +2422,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void finalize_fb_kernel(FinParams p) 
     // Statistics (bench.py's byte accounting): a record per query that only this workgroup updates -- read here,
     // written back at the end with plain stores.  [They were three atomic adds on one shared record: 192 same-line
     // device-scope atomics per search, whose acknowledgements the kernel's end had to wait for.]  p.stats is the
-    // block of PF_STAT_SLOTS / 4 records of this search's WORKSPACE (searches on different streams use different
+    // block of PF_STAT_SLOTS / PF_STAT_WS records of this search's WORKSPACE (searches on different streams use different
     // workspaces and never share a record); a search of more queries than that folds them (counts may be lost;
     // results never depend on them).
-    unsigned long long *const stat = p.stats ? p.stats + (size_t)(q % (PF_STAT_SLOTS / 4)) * 3 : nullptr;
+    unsigned long long *const stat = p.stats ? p.stats + (size_t)(q % (PF_STAT_SLOTS / PF_STAT_WS)) * 3 : nullptr;
     unsigned long long stat_old[3] = {0ull, 0ull, 0ull};
     if (stat && tid == 0 && R == 1) {
         stat_old[0] = stat[0];

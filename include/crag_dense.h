@@ -210,7 +210,7 @@ int crag_index_profile_read_ex(crag_index *ix, int64_t *n_launches, double *scan
 /* Byte accounting of the prefilter path (fp16 MFMA scan + exact fp32 rescoring of the candidates, the path
  * searches over corpora of >= 128 rows per workgroup take): sums since the last call, then cleared.
  * candidates = rows that passed the proven-bound filter, rescored_rows = rows re-read (4 KiB each) for the
- * exact fp32 score.  The records are kept per workspace (= per stream in use, up to four) and per query, written with
+ * exact fp32 score.  The records are kept per workspace (= per stream in use, up to eight) and per query, written with
  * plain stores by the one selection block that owns them: searches overlapping on different streams do not lose counts;
  * a search of more than 256 queries folds its queries onto 256 records and may (results never depend on it).  A search
  * answered by the overflow fallback is not counted.  Synchronises the device. */

@@ -294,9 +294,10 @@ def test_device_resident_late_rows_and_the_token_lane_follow_the_table(gpu):
 
 
 def test_more_streams_than_workspaces_take_over_behind_events(gpu):
-    """The index keeps 4 search workspaces; a 5th .. 7th stream takes over the least recently used one behind
-    the completion event of its last search.  Seven streams cycling three times, nothing synchronised in
-    between: every answer equals the single-stream answer."""
+    """The index keeps 8 search workspaces (the host-buffer search above took the first); the 8th .. 11th stream takes
+    over the least recently used one -- the first time behind a device synchronisation (no event was recorded while
+    workspaces were free), from then on behind the completion event of its last search.  Eleven streams cycling three
+    times, nothing synchronised in between: every answer equals the single-stream answer."""
     import torch
     rng = np.random.default_rng(77)
     n = 40_000
@@ -307,7 +308,7 @@ def test_more_streams_than_workspaces_take_over_behind_events(gpu):
     with DenseIndex(1024, capacity=n) as ix:
         ix.add(corpus)
         want = [ix.search(q, k) for q, (_, k) in zip(qs, shapes)]
-        streams = [torch.cuda.Stream(device=dev) for _ in range(7)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(11)]
         dqs = [torch.from_numpy(q).to(dev) for q in qs]
         torch.cuda.synchronize()
         outs = []
