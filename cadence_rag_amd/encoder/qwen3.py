@@ -469,8 +469,15 @@ class Qwen3Encoder:
             torch.cuda.synchronize(self.device)   # ... once no replay of it can still be running on any stream
             del cache[min(cache, key=lambda k: cache[k]["used"])]
         batch = PackedBatch.build([bucket] * n_seqs, self.device)
-        ids = torch.zeros(n_seqs * bucket, dtype=torch.int32, device=self.device)
-        batch.last_tok = torch.arange(1, n_seqs + 1, dtype=torch.int64, device=self.device) * bucket - 1
+        # the two inputs of a replay -- token ids (int32 [T]) and the pooled rows (int64 [B]) -- live in ONE device
+        # buffer with ONE pinned twin: one upload per forward (two cost a one-query forward a second copy and a second
+        # 18-us host gap in front of the graph: profiles/r04_small_layer_kernel_trace.txt)
+        t_rows = n_seqs * bucket
+        off_last = (4 * t_rows + 7) // 8 * 8
+        d_in = torch.zeros(off_last + 8 * n_seqs, dtype=torch.uint8, device=self.device)
+        ids = d_in[:4 * t_rows].view(torch.int32)
+        batch.last_tok = d_in[off_last:].view(torch.int64)
+        batch.last_tok.copy_(torch.arange(1, n_seqs + 1, dtype=torch.int64, device=self.device) * bucket - 1)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):          # warm-up outside the capture (library handles, autotuning)
@@ -481,9 +488,15 @@ class Qwen3Encoder:
             out = self.forward_packed(ids, batch)
         # pinned staging for the two small uploads of a replay + the event of the last upload (an async copy from a
         # pageable temporary is only safe while the runtime happens to stage it before returning)
+        # TWO pinned twins used in turn, each with the event of the replay that last read it, recorded BEHIND the
+        # replay: no marker packet between the upload and the graph, and the host fills the other buffer while a
+        # forward is still running
+        def pinned():
+            h = torch.zeros(off_last + 8 * n_seqs, dtype=torch.uint8).pin_memory()
+            return {"h_in": h, "h_ids": h[:4 * t_rows].view(torch.int32), "h_last": h[off_last:].view(torch.int64),
+                    "read": torch.cuda.Event()}
         entry = {"graph": graph, "ids": ids, "last_tok": batch.last_tok, "out": out, "batch": batch,
-                 "h_ids": torch.zeros(n_seqs * bucket, dtype=torch.int32).pin_memory(),
-                 "h_last": torch.zeros(n_seqs, dtype=torch.int64).pin_memory(), "uploaded": torch.cuda.Event(),
+                 "d_in": d_in, "pinned": [pinned(), pinned()], "turn": 0,
                  "used": self.__dict__.get("_graph_clock", 0)}
         cache[key] = entry
         return entry
@@ -507,16 +520,17 @@ class Qwen3Encoder:
         if n * bucket in (16, 32):
             self._skinny_weights()      # a flip of CRAG_ENC_SMALL_V1 / CRAG_ENC_NO_SKINNY drops the graphs captured over the other kernels
         g = self._small_graph(n, bucket)
-        g["uploaded"].synchronize()            # the copies of the previous replay have left the pinned buffers
-        host = g["h_ids"].numpy().reshape(n, bucket)
+        pin = g["pinned"][g["turn"]]
+        g["turn"] ^= 1
+        pin["read"].synchronize()              # the replay before last has copied this buffer out
+        host = pin["h_ids"].numpy().reshape(n, bucket)
         host.fill(0)
         for i, (tl, m) in enumerate(zip(token_lists, lens)):
             host[i, :m] = np.asarray(tl[:m], dtype=np.int32)
-        g["h_last"].numpy()[:] = np.arange(n, dtype=np.int64) * bucket + (np.asarray(lens, dtype=np.int64) - 1)
-        g["ids"].copy_(g["h_ids"], non_blocking=True)
-        g["last_tok"].copy_(g["h_last"], non_blocking=True)
-        g["uploaded"].record()
+        pin["h_last"].numpy()[:] = np.arange(n, dtype=np.int64) * bucket + (np.asarray(lens, dtype=np.int64) - 1)
+        g["d_in"].copy_(pin["h_in"], non_blocking=True)
         g["graph"].replay()
+        pin["read"].record()
         return g["out"][:n_real].clone()
 
     @torch.no_grad()
