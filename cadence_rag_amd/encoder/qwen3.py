@@ -507,9 +507,12 @@ class Qwen3Encoder:
         # 33..63 / 97..127 padded rows: phantom sequences round the batch up to 64 / 128 rows, where gate|up and down are
         # the weight-streaming kernels (3 queries of 16 tokens: 3.66 ms through the library's GEMMs at 48 rows, 3.49 ms as
         # 64 rows; 7 queries 4.48 -> 4.22 ms; at 80 / 96 rows the library's 4.0 ms beat the 128-row path's 4.24) -- their
-        # outputs are dropped below
+        # outputs are dropped below.  32 rows as well (one query of 17..32 tokens, two of <= 16: 3.60 ms through the
+        # five-launch layer's 32-row kernels, 3.42-3.46 ms as 64 rows -- profiles/r04_pad32_encode.txt;
+        # CRAG_ENC_NO_PAD_32=1 keeps the 32-row kernels, which also answer when the wide copies do not fit).
         n_real = n
-        if bucket <= 64 and (32 < n * bucket < 64 or 96 < n * bucket < 128) and self._wide_weights() is not None:
+        lo = 31 if os.environ.get("CRAG_ENC_NO_PAD_32") is None else 32
+        if bucket <= 64 and (lo < n * bucket < 64 or 96 < n * bucket < 128) and self._wide_weights() is not None:
             target = 64 if n * bucket < 64 else 128
             if target % bucket == 0:
                 n = target // bucket

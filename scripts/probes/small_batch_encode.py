@@ -13,9 +13,9 @@ def lat(fn, n=30):
     for _ in range(n):
         fn(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n
-for nq in (1, 2, 3, 4, 5, 6, 7, 8, 64):
-    toks = [rng.integers(0, cfg.vocab_size, size=16).tolist() for _ in range(nq)]
-    row = f"nq {nq:2d} x 16 tokens:"
+for nq, ntok in ((1, 16), (1, 24), (1, 32), (2, 16), (3, 16), (4, 16), (5, 16), (6, 16), (7, 16), (8, 16), (64, 16)):
+    toks = [rng.integers(0, cfg.vocab_size, size=ntok).tolist() for _ in range(nq)]
+    row = f"nq {nq:2d} x {ntok} tokens:"
     for wide in (True, False):
         if wide: os.environ.pop("CRAG_ENC_NO_WIDE", None)
         else: os.environ["CRAG_ENC_NO_WIDE"] = "1"

@@ -685,7 +685,8 @@ def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, spl
 
 
 @pytest.mark.parametrize("lens", [[16, 3, 9, 16, 1, 12, 7, 15], [16, 2, 11, 5], [40], [100], [30, 32, 17, 9],
-                                  [16, 5, 9], [16, 3, 9, 16, 1, 12, 7]])   # (the last two: rounded up with phantom sequences)
+                                  [16, 5, 9], [16, 3, 9, 16, 1, 12, 7],    # (these two: rounded up with phantom sequences)
+                                  [20], [32], [5, 16]])                      # (32 rows: run as 64 with a phantom sequence)
 def test_three_to_eight_short_queries_use_the_wide_projections_and_match_transformers(gpu, monkeypatch, lens):
     """The gateway's batch sizes (max_batch_size 8, preferred 1 / 2 / 4 / 8, RUNBOOK:304,331-334): 3 to 8 queries of
     <= 16 tokens, or one query of 33 to 128 tokens = one graph replay over 64 or 128 token rows, whose gate|up + SwiGLU
@@ -718,6 +719,7 @@ def test_one_short_query_takes_the_five_launch_layer_and_matches_transformers(gp
     against the eager packed forward through the library GEMMs and the unfused kernels."""
     model, enc, cfg = _real_width_hf_and_mine()
     rng = np.random.default_rng(5)
+    monkeypatch.setenv("CRAG_ENC_NO_PAD_32", "1")    # 32 rows stay 32 rows here (by default they run as 64: next test)
     for lens in ([9], [16], [1], [20], [32], [5, 16], [12, 3]):
         token_lists = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
         monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
