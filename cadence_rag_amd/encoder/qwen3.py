@@ -345,7 +345,13 @@ class Qwen3Encoder:
         x = torch.empty(t, c.hidden_size, dtype=bf, device=dev)
         ops.embed_gather(ids, self.embed, x)
         # 16 or 32 tokens (one short query): the projections stream their weights (crag_encoder_small.hip)
-        skinny = self._skinny_weights() if t in (16, 32) else None
+        # 32 rows (ONE query of 17..32 tokens, or two of <= 16): gate|up and down through the wide weight-streaming kernels
+        # at 32 rows, qkv / o through the library, one attention launch -- 2.95-3.04 ms against 3.58 through the
+        # five-launch layer's 32-row kernels and 3.34-3.42 padded to 64 rows (profiles/r04_pad32_encode.txt);
+        # CRAG_ENC_NO_WIDE_32=1 (or no room for the wide copies) keeps the five-launch layer
+        wide32 = (t == 32 and os.environ.get("CRAG_ENC_NO_WIDE_32") is None and os.environ.get("CRAG_ENC_SMALL_V1") is None
+                  and self._wide_weights() is not None)
+        skinny = self._skinny_weights() if t in (16, 32) and not wide32 else None
         if skinny is not None and not self._skinny_v1:
             return self._forward_small_rows(x, batch, skinny)
         resid = torch.empty_like(x)
@@ -358,7 +364,7 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
-        wide = self._wide_weights() if t in (64, 128) else None
+        wide = self._wide_weights() if t in (64, 128) or wide32 else None
         short_seqs = (0 < batch.max_len <= 32 and batch.n_seqs <= 65535 and skinny is None
                       and os.environ.get("CRAG_ENC_NO_SHORT_ATTN") is None)
         cs_tok = self._cos_sin.index_select(0, batch.positions.long()) if short_seqs else None   # once per forward
@@ -419,7 +425,7 @@ class Qwen3Encoder:
                 ops.swiglu(gate_up, act)
             if wide is not None:   # ... and down with K split 8 ways (128 rows) / 4 ways (64 rows, 64-row tiles)
                 delta = ops.wide_gemm(act, wide[i]["down"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
-                                      c.hidden_size, 8 if t == 128 else 4)
+                                      c.hidden_size, 8 if t == 128 else 4)   # (32 rows: 4 as well)
             else:
                 delta = F.linear(act, L["down"])
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
@@ -507,18 +513,15 @@ class Qwen3Encoder:
         # 33..63 / 97..127 padded rows: phantom sequences round the batch up to 64 / 128 rows, where gate|up and down are
         # the weight-streaming kernels (3 queries of 16 tokens: 3.66 ms through the library's GEMMs at 48 rows, 3.49 ms as
         # 64 rows; 7 queries 4.48 -> 4.22 ms; at 80 / 96 rows the library's 4.0 ms beat the 128-row path's 4.24) -- their
-        # outputs are dropped below.  32 rows as well (one query of 17..32 tokens, two of <= 16: 3.60 ms through the
-        # five-launch layer's 32-row kernels, 3.42-3.46 ms as 64 rows -- profiles/r04_pad32_encode.txt;
-        # CRAG_ENC_NO_PAD_32=1 keeps the 32-row kernels, which also answer when the wide copies do not fit).
+        # outputs are dropped below.  (32 rows stay 32 rows: the wide kernels take them as they are, forward_packed.)
         n_real = n
-        lo = 31 if os.environ.get("CRAG_ENC_NO_PAD_32") is None else 32
-        if bucket <= 64 and (lo < n * bucket < 64 or 96 < n * bucket < 128) and self._wide_weights() is not None:
+        if bucket <= 64 and (32 < n * bucket < 64 or 96 < n * bucket < 128) and self._wide_weights() is not None:
             target = 64 if n * bucket < 64 else 128
             if target % bucket == 0:
                 n = target // bucket
                 token_lists = list(token_lists) + [[0]] * (n - n_real)
                 lens = list(lens) + [1] * (n - n_real)
-        if n * bucket in (64, 128):
+        if n * bucket in (32, 64, 128):
             self._wide_weights()        # (a flip of CRAG_ENC_NO_WIDE drops the graphs captured over the other kernels)
         if n * bucket in (16, 32):
             self._skinny_weights()      # a flip of CRAG_ENC_SMALL_V1 / CRAG_ENC_NO_SKINNY drops the graphs captured over the other kernels

@@ -1,5 +1,6 @@
-"""Developer probe: one query of 17-32 tokens (and two of 16) as 32 rows through the five-launch layer against the same
-batch padded to 64 rows (the default; CRAG_ENC_NO_PAD_32=1 keeps 32 rows: wide gate|up / down, library qkv / o, one attention launch)."""
+"""Developer probe: one query of 17-32 tokens (and two of 16): 32 rows through the five-launch layer
+(CRAG_ENC_NO_WIDE_32=1), the same batch padded to 64 rows (a third phantom-padded query added here), and 32 rows through
+the wide gate|up / down kernels + library qkv / o + one attention launch (the default)."""
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from cadence_rag_amd.encoder.qwen3 import Qwen3Config, Qwen3Encoder
@@ -19,8 +20,12 @@ def lat(fn, n=40):
 for nq, ntok in ((1, 24), (1, 32), (2, 16)):
     toks = [rng.integers(0, cfg.vocab_size, size=ntok).tolist() for _ in range(nq)]
     row = f"{nq} x {ntok} tokens:"
-    for pad in (False, True):
-        if pad: os.environ.pop("CRAG_ENC_NO_PAD_32", None)
-        else: os.environ["CRAG_ENC_NO_PAD_32"] = "1"
-        row += f"  {'as 64 rows' if pad else 'as 32 rows'} {lat(lambda: enc.embed_token_lists(toks)) * 1e3:6.3f} ms"
+    for mode in ("32 rows, five-launch layer", "as 64 rows", "32 rows, wide kernels"):
+        os.environ.pop("CRAG_ENC_NO_WIDE_32", None)
+        if mode.startswith("32 rows, five"): os.environ["CRAG_ENC_NO_WIDE_32"] = "1"
+        batch = toks
+        if mode == "as 64 rows":   # one more one-token query: 33..63 padded rows round up to 64
+            batch = toks + [[1]]
+        enc.__dict__.pop("_graphs", None)
+        row += f"  {mode} {lat(lambda: enc.embed_token_lists(batch)) * 1e3:6.3f} ms"
     print(row, flush=True)

@@ -656,7 +656,7 @@ def test_small_attention_over_a_packed_batch_of_short_sequences(gpu, lens):
 
 @pytest.mark.parametrize("k,n,swiglu,splitk", [(2560, 6144, False, 4), (4096, 2560, False, 8), (9728, 2560, False, 8),
                                               (9728, 2560, False, 1), (2560, 19456, True, 1), (2560, 19456, True, 3)])
-@pytest.mark.parametrize("m_rows,m_pad", [(128, 128), (97, 128), (64, 64), (33, 64)])
+@pytest.mark.parametrize("m_rows,m_pad", [(128, 128), (97, 128), (64, 64), (33, 64), (32, 32), (17, 32)])
 def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, splitk, m_rows, m_pad):
     """crag_enc_wide_gemm + crag_enc_wide_reduce (the gateway's batch sizes, RUNBOOK:304,331-334: up to 8 short queries
     = 128 token rows) against torch: bf16 operands, fp32 accumulation over K splits added in split order, one rounding;
@@ -686,7 +686,7 @@ def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, spl
 
 @pytest.mark.parametrize("lens", [[16, 3, 9, 16, 1, 12, 7, 15], [16, 2, 11, 5], [40], [100], [30, 32, 17, 9],
                                   [16, 5, 9], [16, 3, 9, 16, 1, 12, 7],    # (these two: rounded up with phantom sequences)
-                                  [20], [32], [5, 16]])                      # (32 rows: run as 64 with a phantom sequence)
+                                  [20], [32], [5, 16]])                      # (32 rows: the wide kernels at 32 rows)
 def test_three_to_eight_short_queries_use_the_wide_projections_and_match_transformers(gpu, monkeypatch, lens):
     """The gateway's batch sizes (max_batch_size 8, preferred 1 / 2 / 4 / 8, RUNBOOK:304,331-334): 3 to 8 queries of
     <= 16 tokens, or one query of 33 to 128 tokens = one graph replay over 64 or 128 token rows, whose gate|up + SwiGLU
@@ -719,7 +719,7 @@ def test_one_short_query_takes_the_five_launch_layer_and_matches_transformers(gp
     against the eager packed forward through the library GEMMs and the unfused kernels."""
     model, enc, cfg = _real_width_hf_and_mine()
     rng = np.random.default_rng(5)
-    monkeypatch.setenv("CRAG_ENC_NO_PAD_32", "1")    # 32 rows stay 32 rows here (by default they run as 64: next test)
+    monkeypatch.setenv("CRAG_ENC_NO_WIDE_32", "1")   # 32 rows through the five-launch layer here (default: the wide kernels)
     for lens in ([9], [16], [1], [20], [32], [5, 16], [12, 3]):
         token_lists = [rng.integers(0, cfg.vocab_size, size=n).tolist() for n in lens]
         monkeypatch.delenv("CRAG_ENC_NO_GRAPH", raising=False)
