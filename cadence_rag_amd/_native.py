@@ -77,6 +77,8 @@ SIGNATURES = {
     "crag_enc_wide_gemm": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "crag_enc_wide_gemm_direct": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
     "crag_enc_wide_reduce": (_c.c_int, [_P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "crag_enc_wide_gemm_rows": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    "crag_enc_rmsnorm_partials": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_float, _P]),
     "crag_enc_small_attention": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                             _c.c_float, _P]),
     "crag_enc_small_attention_seqs": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int,

@@ -94,6 +94,7 @@ struct WideParams {
     u16 *out;          // direct output (splitk == 1): [m_rows, ld_out] bf16
     int K, n32, splitk;
     int m_rows, ld_out, epilogue;
+    int token_major;   // partial as [splitk][32 MG tokens][N] fp32 rows (what crag_enc_rmsnorm_partials reads) instead
 };
 
 // bf16 output of one wave's 32 x 32 accumulator tile (D[row 8 b + 4 h + c][token] = acc[4 b + c]); epilogue 1: the 32
@@ -256,6 +257,17 @@ __global__ __launch_bounds__(64 * WV) void wide_gemm_kernel(WideParams p) {
         }
         return;
     }
+    if (p.token_major) {   // partial[split][token][32 n32 + 8 b + 4 h + c]: a consumer that works row by row reads it coalesced
+        const int h = lane >> 5;
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+            float *row = p.partial + ((size_t)split * (32 * MG) + 32 * mg + (lane & 31)) * ((size_t)p.n32 * 32) + 32 * n32 + 4 * h;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                *reinterpret_cast<f32x4_t *>(row + 8 * b) = f32x4_t{acc[mg][4 * b], acc[mg][4 * b + 1], acc[mg][4 * b + 2], acc[mg][4 * b + 3]};
+        }
+        return;
+    }
     // D[row 8 b + 4 h + c][token j] = acc[4 b + c] of lane (h, j): stored as they are, 16 bytes per lane and b
     f32x4_t *out = reinterpret_cast<f32x4_t *>(p.partial) + (((size_t)split * p.n32 + n32) * MG) * 4 * 64 + lane;
 #pragma unroll
@@ -291,6 +303,69 @@ __global__ __launch_bounds__(WIDE_THREADS) void wide_reduce_kernel(WideReducePar
     }
     if (token >= p.m_rows) return;
     wide_store(p.out, p.ld_out, n32, token, h, sum, p.epilogue);
+}
+
+// The residual add + RMSNorm that follows a split-K projection, reading its TOKEN-MAJOR partial tiles directly:
+// delta = bf16(sum over the splits, in split order) -- the rounding of crag_enc_wide_reduce --, then crag_enc_rmsnorm's
+// arithmetic (bf16 residual add, fp32 statistics, bf16(x * rstd) * w).  One workgroup per token row; replaces the reduce
+// launch + the norm launch (about 5 us each at these sizes).
+struct NormPartialsParams {
+    const float *partial;   // [splitk][m_pad][hidden]
+    const u16 *res_in, *w;
+    u16 *out, *res_out;
+    int splitk, m_pad, hidden, rows;
+    float eps;
+};
+
+__global__ __launch_bounds__(WIDE_THREADS) void rmsnorm_partials_kernel(NormPartialsParams p) {
+    __shared__ float sh[WIDE_THREADS / 64];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    constexpr int MAXC = 4;                       // hidden <= 4 * 256 * 4 = 4096
+    const int chunks = p.hidden >> 2;             // 4 columns (one f32x4 of a partial row) per step
+    float v[MAXC][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + i * WIDE_THREADS;
+        if (c < chunks) {
+            f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < p.splitk; ++s)
+                sum += *reinterpret_cast<const f32x4_t *>(p.partial + ((size_t)s * p.m_pad + r) * p.hidden + 4 * c);
+            const uint2 rr = *reinterpret_cast<const uint2 *>(p.res_in + (size_t)r * p.hidden + 4 * c);
+            const u16 rin[4] = {(u16)(rr.x & 0xffffu), (u16)(rr.x >> 16), (u16)(rr.y & 0xffffu), (u16)(rr.y >> 16)};
+            u16 s4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s4[e] = f2bf(bf2f(f2bf(sum[e])) + bf2f(rin[e]));   // delta rounded once, then the bf16 residual add
+                v[i][e] = bf2f(s4[e]);
+                ss += v[i][e] * v[i][e];
+            }
+            if (p.res_out)
+                *reinterpret_cast<uint2 *>(p.res_out + (size_t)r * p.hidden + 4 * c) =
+                    make_uint2((uint32_t)s4[0] | ((uint32_t)s4[1] << 16), (uint32_t)s4[2] | ((uint32_t)s4[3] << 16));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((tid & 63) == 0) sh[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < WIDE_THREADS / 64; ++i) tot += sh[i];
+    const float rstd = rsqrtf(tot / (float)p.hidden + p.eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = tid + i * WIDE_THREADS;
+        if (c < chunks) {
+            const uint2 ww = *reinterpret_cast<const uint2 *>(p.w + 4 * c);
+            const u16 w4[4] = {(u16)(ww.x & 0xffffu), (u16)(ww.x >> 16), (u16)(ww.y & 0xffffu), (u16)(ww.y >> 16)};
+            u16 o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(bf2f(w4[e]) * bf2f(f2bf(v[i][e] * rstd)));
+            *reinterpret_cast<uint2 *>(p.out + (size_t)r * p.hidden + 4 * c) =
+                make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+    }
 }
 
 // 128-row tiles (4 waves) unless they give the chip fewer than 100 workgroups: then 64-row tiles (2 waves, twice the
@@ -340,8 +415,51 @@ int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, in
     p.K = k;
     p.n32 = n / 32;
     p.splitk = splitk;
+    p.token_major = 0;
     wide_launch(p, m_pad, n, (hipStream_t)stream);
     return whip_ok("wide_gemm");
+}
+
+int crag_enc_wide_gemm_rows(const uint16_t *x, const uint16_t *ww, float *partial, int m_pad, int n, int k, int splitk,
+                            void *stream) {
+    if (!x || !ww || !partial) return wfail("wide_gemm_rows: NULL pointer");
+    if (m_pad != 32 && m_pad != 64 && m_pad != 128) return wfail("wide_gemm_rows: m_pad must be 32, 64 or 128 (got %d)", m_pad);
+    if (n <= 0 || n % 128) return wfail("wide_gemm_rows: n must be a multiple of 128 (got %d)", n);
+    if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm_rows: k must be a multiple of %d (got %d)", WIDE_BK, k);
+    if (splitk <= 0 || splitk > k / WIDE_BK) return wfail("wide_gemm_rows: splitk must be in [1, k / %d] (got %d)", WIDE_BK, splitk);
+    WideParams p;
+    p.x = x;
+    p.ww = ww;
+    p.partial = partial;
+    p.out = nullptr;
+    p.m_rows = p.ld_out = p.epilogue = 0;
+    p.K = k;
+    p.n32 = n / 32;
+    p.splitk = splitk;
+    p.token_major = 1;
+    wide_launch(p, m_pad, n, (hipStream_t)stream);
+    return whip_ok("wide_gemm_rows");
+}
+
+int crag_enc_rmsnorm_partials(const float *partial_rows, int splitk, int m_pad, const uint16_t *residual_in,
+                              const uint16_t *weight, uint16_t *out, uint16_t *residual_out, int rows, int hidden,
+                              float eps, void *stream) {
+    if (!partial_rows || !residual_in || !weight || !out) return wfail("rmsnorm_partials: NULL pointer");
+    if (splitk <= 0 || rows <= 0 || rows > m_pad) return wfail("rmsnorm_partials: need splitk > 0 and 0 < rows <= m_pad");
+    if (hidden <= 0 || hidden % 4 || hidden > 4096) return wfail("rmsnorm_partials: hidden must be a multiple of 4, at most 4096");
+    NormPartialsParams p;
+    p.partial = partial_rows;
+    p.res_in = residual_in;
+    p.w = weight;
+    p.out = out;
+    p.res_out = residual_out;
+    p.splitk = splitk;
+    p.m_pad = m_pad;
+    p.hidden = hidden;
+    p.rows = rows;
+    p.eps = eps;
+    hipLaunchKernelGGL(rmsnorm_partials_kernel, dim3((unsigned)rows), dim3(WIDE_THREADS), 0, (hipStream_t)stream, p);
+    return whip_ok("rmsnorm_partials");
 }
 
 int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *out, int m_rows, int m_pad, int n, int k,
@@ -363,6 +481,7 @@ int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *o
     p.K = k;
     p.n32 = n / 32;
     p.splitk = 1;
+    p.token_major = 0;
     wide_launch(p, m_pad, n, (hipStream_t)stream);
     return whip_ok("wide_gemm_direct");
 }

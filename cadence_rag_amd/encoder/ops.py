@@ -214,3 +214,34 @@ def wide_gemm(x: torch.Tensor, ww: torch.Tensor, out: torch.Tensor, m_rows: int,
     _native.check(lib.crag_enc_wide_reduce(_p(scratch), _p(out), int(m_rows), int(m_pad), int(n), int(splitk),
                                            1 if swiglu else 0, _stream()), "crag_enc_wide_reduce")
     return out
+
+
+def wide_gemm_rows(x: torch.Tensor, ww: torch.Tensor, n: int, splitk: int, scratch: "torch.Tensor | None" = None):
+    """The split-K half of wide_gemm alone, its fp32 partial tiles TOKEN-MAJOR ([splitk, m_pad, n]) for
+    rmsnorm_partials to consume (crag_enc_wide_gemm_rows).  Returns the scratch tensor that holds them: the per-device
+    buffer unless one is passed -- valid until the next split-K wide_gemm / wide_gemm_rows on that device."""
+    _req(x, torch.bfloat16, "x"); _req(ww, torch.bfloat16, "ww")
+    m_pad, k = x.shape
+    need = int(splitk) * int(n) * int(m_pad)
+    if scratch is None:
+        scratch = _wide_scratch.get(x.device)
+        if scratch is None or scratch.numel() < need:
+            scratch = _wide_scratch[x.device] = torch.empty(max(need, 4 * 19456 * 128), dtype=torch.float32, device=x.device)
+    elif scratch.dtype != torch.float32 or scratch.numel() < need:
+        raise ValueError("scratch must be a float32 tensor of at least splitk * n * m_pad elements")
+    _native.check(_native.load().crag_enc_wide_gemm_rows(_p(x), _p(ww), _p(scratch), int(m_pad), int(n), int(k), int(splitk),
+                                                         _stream()), "crag_enc_wide_gemm_rows")
+    return scratch
+
+
+def rmsnorm_partials(partial_rows: torch.Tensor, splitk: int, m_pad: int, weight: torch.Tensor, out: torch.Tensor,
+                     eps: float, residual_in: torch.Tensor, residual_out: "torch.Tensor | None"):
+    """out = RMSNorm(residual_in + bf16(sum of the splitk token-major partial tiles)) * weight; residual_out <- the sum
+    (crag_enc_rmsnorm_partials: wide_reduce + rmsnorm in one launch, the same roundings)."""
+    _req(partial_rows, torch.float32, "partial_rows"); _req(weight, torch.bfloat16, "weight"); _req(out, torch.bfloat16, "out")
+    _req(residual_in, torch.bfloat16, "residual_in")
+    rows, hidden = out.shape
+    _native.check(_native.load().crag_enc_rmsnorm_partials(_p(partial_rows), int(splitk), int(m_pad), _p(residual_in), _p(weight),
+                                                           _p(out), _p(residual_out), int(rows), int(hidden), float(eps),
+                                                           _stream()), "crag_enc_rmsnorm_partials")
+    return out

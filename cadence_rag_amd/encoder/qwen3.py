@@ -256,7 +256,7 @@ class Qwen3Encoder:
         return self._skinny
 
     def _wide_weights(self):
-        """gate|up and down a second time in the fragment order crag_enc_wide_gemm streams (+ 5.4 GB for the 4B model),
+        """gate|up, down and o a second time in the fragment order crag_enc_wide_gemm streams (+ 6.1 GB for the 4B model),
         for forwards of exactly 64 or 128 token rows (3 to 8 queries of <= 16 tokens: the gateway's batch sizes,
         RUNBOOK:304,331-334).  Those are the projections where the weight-streaming kernel beats the library's small-M
         GEMM (profiles/r04_wide_gemm.txt, per layer at 128 rows: gate|up + SwiGLU 29.0 vs 37.2 us in ONE launch, down 24.1
@@ -271,8 +271,8 @@ class Qwen3Encoder:
             return None
         if self.__dict__.get("_wide") is None:
             try:
-                self._wide = [{"gate_up": ops.wide_gate_up_weight(L["gate_up"]), "down": ops.wide_weight(L["down"])}
-                              for L in self.layers]
+                self._wide = [{"gate_up": ops.wide_gate_up_weight(L["gate_up"]), "down": ops.wide_weight(L["down"]),
+                               "o": ops.wide_weight(L["o"])} for L in self.layers]
             except torch.OutOfMemoryError:
                 self._wide, self._wide_failed = None, True
                 torch.cuda.empty_cache()
@@ -369,10 +369,16 @@ class Qwen3Encoder:
                       and os.environ.get("CRAG_ENC_NO_SHORT_ATTN") is None)
         cs_tok = self._cos_sin.index_select(0, batch.positions.long()) if short_seqs else None   # once per forward
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
+        down_parts, down_split = None, (8 if t == 128 else 4)
+        fuse_reduce = os.environ.get("CRAG_ENC_NO_FUSED_REDUCE") is None
         for i, L in enumerate(self.layers):
             if i == 0:
                 ops.rmsnorm(x, L["ln1"], normed, c.rms_norm_eps, residual_in=None, residual_out=None)
                 resid.copy_(x)
+            elif down_parts is not None:   # the previous layer's down left its split-K partial tiles: summed by the norm
+                ops.rmsnorm_partials(down_parts, down_split, t, L["ln1"], normed, c.rms_norm_eps, residual_in=resid,
+                                     residual_out=resid)
+                down_parts = None
             else:
                 ops.rmsnorm(delta, L["ln1"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             # hipBLASLt picks a ~13 % faster kernel for this shape (K 2560, N 6144) at M = 32768 than at 65536
@@ -416,16 +422,26 @@ class Qwen3Encoder:
                 delta = ops.skinny_gemm(act, skinny[i]["down"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
                                         c.hidden_size)
                 continue
-            delta = F.linear(attn, L["o"])
-            ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
+            if wide is not None and fuse_reduce:
+                # o with K split 4 ways through the wide kernel, its token-major partial tiles summed by the norm that
+                # consumes them: the library's GEMM + a norm launch (at 128 rows 18.8 + 5 us) become 13 + 5
+                o_parts = ops.wide_gemm_rows(attn, wide[i]["o"], c.hidden_size, 4)
+                ops.rmsnorm_partials(o_parts, 4, t, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
+            else:
+                delta = F.linear(attn, L["o"])
+                ops.rmsnorm(delta, L["ln2"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             if wide is not None:   # 64 / 128 rows: gate|up + SwiGLU as ONE weight-streaming launch (crag_encoder_wide.hip)
                 ops.wide_gemm(normed, wide[i]["gate_up"], act, t, 2 * c.intermediate_size, 1, swiglu=True)
             else:
                 gate_up = F.linear(normed, L["gate_up"])
                 ops.swiglu(gate_up, act)
-            if wide is not None:   # ... and down with K split 8 ways (128 rows) / 4 ways (64 rows, 64-row tiles)
+            if wide is not None and i + 1 < len(self.layers) and fuse_reduce:
+                # ... and down with K split 8 ways (128 rows) / 4 ways (64 and 32 rows, 64-row tiles); its partial tiles
+                # stay in fp32, token-major, for the next layer's norm to sum (no reduce launch)
+                down_parts, delta = ops.wide_gemm_rows(act, wide[i]["down"], c.hidden_size, down_split), None
+            elif wide is not None:
                 delta = ops.wide_gemm(act, wide[i]["down"], torch.empty(t, c.hidden_size, dtype=bf, device=dev), t,
-                                      c.hidden_size, 8 if t == 128 else 4)   # (32 rows: 4 as well)
+                                      c.hidden_size, down_split)
             else:
                 delta = F.linear(act, L["down"])
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)

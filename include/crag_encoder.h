@@ -152,6 +152,16 @@ int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *o
                               int epilogue, void *stream);
 int crag_enc_wide_reduce(const float *partial, uint16_t *out, int m_rows, int m_pad, int n, int splitk, int epilogue,
                          void *stream);
+/* A split-K projection whose consumer is the residual add + RMSNorm of the next sub-block (down -> ln1): the partial
+ * tiles TOKEN-MAJOR, partial_rows[splitk][m_pad][n] fp32 (crag_enc_wide_partial_bytes bytes as well), and the norm that
+ * reads them -- delta = bf16(sum over the splits, in split order), the rounding of crag_enc_wide_reduce, then
+ * crag_enc_rmsnorm's arithmetic with residual_in (required) / residual_out (nullable; may alias residual_in): two
+ * launches (reduce, norm) become one.  hidden = n <= 4096. */
+int crag_enc_wide_gemm_rows(const uint16_t *x, const uint16_t *ww, float *partial_rows, int m_pad, int n, int k, int splitk,
+                            void *stream);
+int crag_enc_rmsnorm_partials(const float *partial_rows, int splitk, int m_pad, const uint16_t *residual_in,
+                              const uint16_t *weight, uint16_t *out, uint16_t *residual_out, int rows, int hidden,
+                              float eps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -684,6 +684,35 @@ def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, spl
         assert torch.allclose(got, want.float().cpu(), atol=3e-3, rtol=3e-2), (got - want.float().cpu()).abs().max()
 
 
+@pytest.mark.parametrize("m_rows,m_pad,splitk", [(32, 32, 4), (17, 32, 4), (64, 64, 4), (50, 64, 2), (128, 128, 8), (99, 128, 8)])
+def test_split_k_partials_summed_by_the_norm_that_consumes_them(gpu, m_rows, m_pad, splitk):
+    """crag_enc_wide_gemm_rows (the split-K partial tiles token-major) + crag_enc_rmsnorm_partials (sum of the splits,
+    residual add, RMSNorm in ONE launch) against wide_gemm (partials + reduce launch) + rmsnorm: the same bits for the
+    normed rows and for the new residual stream -- the down projection -> next layer's ln1 hand-off of the 32 / 64 /
+    128-row forward."""
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(m_rows * 7 + splitk)
+    k, n = 9728, 2560
+    w = _bf(torch.randn(n, k, generator=g) * 0.02)
+    ww = ops.wide_weight(w)
+    x = _bf(torch.randn(m_pad, k, generator=g))
+    resid = _bf(torch.randn(m_rows, n, generator=g))
+    nw = _bf(1 + 0.1 * torch.randn(n, generator=g))
+    delta = torch.empty(m_rows, n, dtype=BF, device=DEV)
+    ops.wide_gemm(x, ww, delta, m_rows, n, splitk)
+    want_norm, want_res = torch.empty_like(delta), torch.empty_like(delta)
+    ops.rmsnorm(delta, nw, want_norm, 1e-6, residual_in=resid, residual_out=want_res)
+    scratch = torch.full((splitk * n * m_pad + 64,), float("nan"), dtype=torch.float32, device=DEV)
+    parts = ops.wide_gemm_rows(x, ww, n, splitk, scratch=scratch)
+    got_norm = torch.full((m_rows + 1, n), 9.0, dtype=BF, device=DEV)
+    res_io = resid.clone()                                        # residual_out aliases residual_in, as the forward does
+    ops.rmsnorm_partials(parts, splitk, m_pad, nw, got_norm[:m_rows], 1e-6, residual_in=res_io, residual_out=res_io)
+    torch.cuda.synchronize()
+    assert torch.all(torch.isnan(scratch[splitk * n * m_pad:])) and torch.all(got_norm[m_rows] == 9.0)
+    assert torch.equal(res_io, want_res)
+    assert torch.equal(got_norm[:m_rows], want_norm)
+
+
 @pytest.mark.parametrize("lens", [[16, 3, 9, 16, 1, 12, 7, 15], [16, 2, 11, 5], [40], [100], [30, 32, 17, 9],
                                   [16, 5, 9], [16, 3, 9, 16, 1, 12, 7],    # (these two: rounded up with phantom sequences)
                                   [20], [32], [5, 16]])                      # (32 rows: the wide kernels at 32 rows)
