@@ -83,6 +83,8 @@ SIGNATURES = {
                                             _c.c_float, _P]),
     "crag_enc_small_attention_seqs": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _c.c_int, _P, _c.c_int,
                                                  _c.c_int, _c.c_float, _c.c_float, _P]),
+    "crag_enc_small_attention_seqs_parts": (_c.c_int, [_P, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _c.c_int,
+                                                       _c.c_int, _P, _c.c_int, _c.c_int, _c.c_float, _c.c_float, _P]),
 }
 
 

@@ -271,6 +271,8 @@ struct SmallAttnParams {
     const int32_t *positions;
     u16 *out;  // [T, hq * 128]
     const int32_t *cu;  // NULL: ONE block of n_tokens rows; else [gridDim.y + 1]: block y = rows cu[y] .. cu[y + 1] - 1 (one sequence)
+    const float *parts; // nullable: the qkv projection as split-K partial tiles [splitk][m_pad][width] fp32 (token-major) instead
+    int splitk, m_pad;  //           of qkv: a head vector = bf16(sum over the splits, in split order)
     int n_tokens, hq, hkv, cs_by_token;
     float eps, scale_log2;
 };
@@ -304,6 +306,19 @@ __global__ __launch_bounds__(256 * QB) void small_attn_kernel(SmallAttnParams p)
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[i].v[e] = 0;
         if (t < ntok) {
+            if (p.parts) {   // the projection's split-K partial tiles: summed and rounded here (no reduce launch)
+                f32x4_t lo = f32x4_t{0.f, 0.f, 0.f, 0.f}, hi = lo;
+                for (int s = 0; s < p.splitk; ++s) {
+                    const float *src = p.parts + ((int64_t)s * p.m_pad + tok0 + t) * row_stride + (int64_t)head * CRAG_HEAD_DIM + sub * 8;
+                    lo += *reinterpret_cast<const f32x4_t *>(src);
+                    hi += *reinterpret_cast<const f32x4_t *>(src + 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    raw[i].v[e] = f2bf(lo[e]);
+                    raw[i].v[4 + e] = f2bf(hi[e]);
+                }
+            } else
             raw[i] = *reinterpret_cast<const Pack8s *>(p.qkv + (tok0 + t) * row_stride + (int64_t)head * CRAG_HEAD_DIM + sub * 8);
             if (which != 2) {
                 // a table gathered per token (once per forward) takes a dependent load out of every layer's chain
@@ -492,6 +507,8 @@ int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, cons
     p.hq = hq;
     p.hkv = hkv;
     p.cu = nullptr;
+    p.parts = nullptr;
+    p.splitk = p.m_pad = 0;
     p.cs_by_token = cos_sin_by_token != 0;
     p.eps = eps;
     p.scale_log2 = scale * 1.4426950408889634f;
@@ -500,11 +517,34 @@ int crag_enc_small_attention(const uint16_t *qkv, const uint16_t *q_norm_w, cons
     return hip_ok("small_attention");
 }
 
+static int small_attention_seqs_impl(const uint16_t *qkv, const float *parts, int splitk, int m_pad, const uint16_t *q_norm_w,
+                                     const uint16_t *k_norm_w, const float *cos_sin, int cos_sin_by_token,
+                                     const int32_t *positions, const int32_t *cu_seqlens, int n_seqs, int max_len,
+                                     uint16_t *out, int hq, int hkv, float eps, float scale, void *stream);
+
 int crag_enc_small_attention_seqs(const uint16_t *qkv, const uint16_t *q_norm_w, const uint16_t *k_norm_w,
                                   const float *cos_sin, int cos_sin_by_token, const int32_t *positions,
                                   const int32_t *cu_seqlens, int n_seqs, int max_len, uint16_t *out, int hq, int hkv,
                                   float eps, float scale, void *stream) {
-    if (!qkv || !q_norm_w || !k_norm_w || !cos_sin || !positions || !cu_seqlens || !out)
+    if (!qkv) return efail("small_attention_seqs: NULL pointer");
+    return small_attention_seqs_impl(qkv, nullptr, 0, 0, q_norm_w, k_norm_w, cos_sin, cos_sin_by_token, positions, cu_seqlens,
+                                     n_seqs, max_len, out, hq, hkv, eps, scale, stream);
+}
+
+int crag_enc_small_attention_seqs_parts(const float *qkv_partial_rows, int splitk, int m_pad, const uint16_t *q_norm_w,
+                                        const uint16_t *k_norm_w, const float *cos_sin, int cos_sin_by_token,
+                                        const int32_t *positions, const int32_t *cu_seqlens, int n_seqs, int max_len,
+                                        uint16_t *out, int hq, int hkv, float eps, float scale, void *stream) {
+    if (!qkv_partial_rows || splitk <= 0 || m_pad <= 0) return efail("small_attention_seqs_parts: NULL pointer / bad split");
+    return small_attention_seqs_impl(nullptr, qkv_partial_rows, splitk, m_pad, q_norm_w, k_norm_w, cos_sin, cos_sin_by_token,
+                                     positions, cu_seqlens, n_seqs, max_len, out, hq, hkv, eps, scale, stream);
+}
+
+static int small_attention_seqs_impl(const uint16_t *qkv, const float *parts, int splitk, int m_pad, const uint16_t *q_norm_w,
+                                     const uint16_t *k_norm_w, const float *cos_sin, int cos_sin_by_token,
+                                     const int32_t *positions, const int32_t *cu_seqlens, int n_seqs, int max_len,
+                                     uint16_t *out, int hq, int hkv, float eps, float scale, void *stream) {
+    if ((!qkv && !parts) || !q_norm_w || !k_norm_w || !cos_sin || !positions || !cu_seqlens || !out)
         return efail("small_attention_seqs: NULL pointer");
     if (n_seqs <= 0 || n_seqs > 65535) return efail("small_attention_seqs: 1..65535 sequences (got %d)", n_seqs);
     if (max_len <= 0 || max_len > 32) return efail("small_attention_seqs: sequences of 1..32 tokens (max_len %d)", max_len);
@@ -517,6 +557,9 @@ int crag_enc_small_attention_seqs(const uint16_t *qkv, const uint16_t *q_norm_w,
     p.positions = positions;
     p.out = out;
     p.cu = cu_seqlens;
+    p.parts = parts;
+    p.splitk = splitk;
+    p.m_pad = m_pad;
     p.n_tokens = 0;
     p.hq = hq;
     p.hkv = hkv;

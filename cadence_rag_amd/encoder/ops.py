@@ -167,6 +167,21 @@ def small_attention_seqs(qkv, q_w, k_w, cos_sin, positions, cu, n_seqs: int, max
     return out
 
 
+def small_attention_seqs_parts(parts, splitk: int, m_pad: int, q_w, k_w, cos_sin, positions, cu, n_seqs: int, max_len: int,
+                               out, hq: int, hkv: int, eps: float, scale: float, by_token: bool = False):
+    """small_attention_seqs over the qkv projection's split-K partial tiles (wide_gemm_rows): the head vectors are summed
+    over the splits and rounded to bf16 while they are loaded (crag_enc_small_attention_seqs_parts)."""
+    _req(parts, torch.float32, "parts"); _req(cos_sin, torch.float32, "cos_sin"); _req(positions, torch.int32, "positions")
+    _req(out, torch.bfloat16, "out"); _req(q_w, torch.bfloat16, "q_w"); _req(k_w, torch.bfloat16, "k_w")
+    _req(cu, torch.int32, "cu")
+    _native.check(_native.load().crag_enc_small_attention_seqs_parts(_p(parts), int(splitk), int(m_pad), _p(q_w), _p(k_w),
+                                                                     _p(cos_sin), 1 if by_token else 0, _p(positions),
+                                                                     _p(cu), int(n_seqs), int(max_len), _p(out), hq, hkv,
+                                                                     float(eps), float(scale), _stream()),
+                  "crag_enc_small_attention_seqs_parts")
+    return out
+
+
 # -- the linear layers at 64 / 128 token rows (csrc/crag_encoder_wide.hip) ------------------------------------------
 def wide_weight(weight: torch.Tensor) -> torch.Tensor:
     """[n, k] bf16 (torch Linear layout) -> the A-fragment order of v_mfma_f32_32x32x16_bf16 that crag_enc_wide_gemm

@@ -256,7 +256,7 @@ class Qwen3Encoder:
         return self._skinny
 
     def _wide_weights(self):
-        """gate|up, down and o a second time in the fragment order crag_enc_wide_gemm streams (+ 6.1 GB for the 4B model),
+        """All four projections a second time in the fragment order crag_enc_wide_gemm streams (+ 7.3 GB for the 4B model),
         for forwards of exactly 64 or 128 token rows (3 to 8 queries of <= 16 tokens: the gateway's batch sizes,
         RUNBOOK:304,331-334).  Those are the projections where the weight-streaming kernel beats the library's small-M
         GEMM (profiles/r04_wide_gemm.txt, per layer at 128 rows: gate|up + SwiGLU 29.0 vs 37.2 us in ONE launch, down 24.1
@@ -272,7 +272,7 @@ class Qwen3Encoder:
         if self.__dict__.get("_wide") is None:
             try:
                 self._wide = [{"gate_up": ops.wide_gate_up_weight(L["gate_up"]), "down": ops.wide_weight(L["down"]),
-                               "o": ops.wide_weight(L["o"])} for L in self.layers]
+                               "o": ops.wide_weight(L["o"]), "qkv": ops.wide_weight(L["qkv"])} for L in self.layers]
             except torch.OutOfMemoryError:
                 self._wide, self._wide_failed = None, True
                 torch.cuda.empty_cache()
@@ -383,12 +383,21 @@ class Qwen3Encoder:
                 ops.rmsnorm(delta, L["ln1"], normed, c.rms_norm_eps, residual_in=resid, residual_out=resid)
             # hipBLASLt picks a ~13 % faster kernel for this shape (K 2560, N 6144) at M = 32768 than at 65536
             # (scripts/probes/gemm_layouts.py), so large batches run the projection in row chunks
-            if skinny is not None:
+            qkv_parts = None
+            if wide is not None and fuse_reduce and short_seqs and os.environ.get("CRAG_ENC_NO_WIDE_QKV") is None:
+                # qkv with K split 2 ways through the wide kernel; the attention kernel sums the two partial tiles of
+                # every head vector while it loads them
+                qkv_parts = ops.wide_gemm_rows(normed, wide[i]["qkv"], width, 2)
+            elif skinny is not None:
                 ops.skinny_gemm(normed, skinny[i]["qkv"], qkv, t, width)
-            for lo in range(0, t if skinny is None else 0, QKV_ROW_CHUNK):
+            for lo in range(0, t if skinny is None and qkv_parts is None else 0, QKV_ROW_CHUNK):
                 hi = min(t, lo + QKV_ROW_CHUNK)
                 torch.matmul(normed[lo:hi], L["qkv"].t(), out=qkv[lo:hi])
-            if short_seqs:
+            if qkv_parts is not None:
+                ops.small_attention_seqs_parts(qkv_parts, 2, t, L["q_norm"], L["k_norm"], cs_tok, batch.positions, batch.cu,
+                                               batch.n_seqs, batch.max_len, attn, c.num_heads, c.num_kv_heads,
+                                               c.rms_norm_eps, scale, by_token=True)
+            elif short_seqs:
                 # every sequence <= 32 tokens (a batch of short queries): q/k-norm + RoPE + attention in ONE launch, a
                 # workgroup per (q head, sequence), instead of the rope / V-transpose launch + the flash kernel
                 ops.small_attention_seqs(qkv, L["q_norm"], L["k_norm"], cs_tok, batch.positions, batch.cu, batch.n_seqs,

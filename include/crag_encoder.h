@@ -128,6 +128,13 @@ int crag_enc_small_attention_seqs(const uint16_t *qkv, const uint16_t *q_norm_w,
                                   const float *cos_sin, int cos_sin_by_token, const int32_t *positions,
                                   const int32_t *cu_seqlens, int n_seqs, int max_len, uint16_t *out, int hq, int hkv,
                                   float eps, float scale, void *stream);
+/* The same with the qkv projection handed over as the split-K partial tiles of crag_enc_wide_gemm_rows
+ * (qkv_partial_rows[splitk][m_pad][(hq + 2 hkv) * 128] fp32): every head vector is bf16(sum over the splits, in split
+ * order) -- what crag_enc_wide_reduce would have written -- summed while it is loaded. */
+int crag_enc_small_attention_seqs_parts(const float *qkv_partial_rows, int splitk, int m_pad, const uint16_t *q_norm_w,
+                                        const uint16_t *k_norm_w, const float *cos_sin, int cos_sin_by_token,
+                                        const int32_t *positions, const int32_t *cu_seqlens, int n_seqs, int max_len,
+                                        uint16_t *out, int hq, int hkv, float eps, float scale, void *stream);
 
 /* ---- the linear layers at 32 / 64 / 128 token rows: what the gateway's batcher hands the model (RUNBOOK:304,331-334:
  * max_batch_size 8, preferred_batch_size [1, 2, 4, 8]) -- csrc/crag_encoder_wide.hip ----

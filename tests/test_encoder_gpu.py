@@ -642,6 +642,19 @@ def test_small_attention_over_a_packed_batch_of_short_sequences(gpu, lens):
     old = torch.empty(t, hq * 128, dtype=BF, device=DEV)
     ops.attention(work, vt, old, batch.cu, batch.cu_pad, batch.blk_seq, batch.blk_q0, hq, hkv, 1 / math.sqrt(128))
     assert torch.allclose(got, old.float().cpu().view(t, hq, 128), atol=2e-2, rtol=2e-2)
+    # the same projection handed over as two split-K partial tiles (fp32, token-major): summed and rounded while loaded
+    m_pad = (t + 31) // 32 * 32
+    a = torch.randn(m_pad, qkv.shape[1], generator=g).to(DEV) * 0.5
+    parts = torch.zeros(2, m_pad, qkv.shape[1], dtype=torch.float32, device=DEV)
+    parts[0, :t], parts[1, :t] = a[:t], qkv[:t].float() - a[:t]   # (fp32 sums that round back to the bf16 values)
+    rounded = (parts[0, :t] + parts[1, :t]).to(BF)
+    from_parts = torch.full_like(out, 5.0)
+    ops.small_attention_seqs_parts(parts, 2, m_pad, qw, kw, cs_tok, batch.positions, batch.cu, len(lens), batch.max_len,
+                                   from_parts[:t], hq, hkv, 1e-6, 1 / math.sqrt(128), by_token=True)
+    direct = torch.full_like(out, 5.0)
+    ops.small_attention_seqs(rounded, qw, kw, cs_tok, batch.positions, batch.cu, len(lens), batch.max_len, direct[:t], hq, hkv,
+                             1e-6, 1 / math.sqrt(128), by_token=True)
+    assert torch.equal(from_parts, direct)
     # each sequence by itself through the one-block entry point (the block size is picked per call there: compare the
     # sequences whose own length picks the same kernel as the batch's longest)
     lo = 0
