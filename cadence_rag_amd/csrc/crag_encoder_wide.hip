@@ -146,8 +146,8 @@ __global__ __launch_bounds__(64 * WV) void wide_gemm_kernel(WideParams p) {
     // multiples of 512 bytes): a 16-way conflict, 1.7 us of LDS time per chunk against 0.43 us of MFMAs.  The readers
     // apply the same XOR (a permutation inside each 16-lane phase: their reads stay conflict-free).
     constexpr int PPR = 2 * WIDE_KS;                              // 16-byte pieces per token row and chunk
-    constexpr int PIECES = MG * 32 * PPR / WIDE_THREADS;          // per thread: 2 (32 rows), 4 (64 rows) or 8 (128 rows)
-    static_assert(PIECES == 2 || PIECES == 4 || PIECES == 8, "the staging waits name their registers");
+    constexpr int PIECES = MG * 32 * PPR / WIDE_THREADS;          // per thread: 2 (32 rows), 4 (64), 6 (96) or 8 (128 rows)
+    static_assert(PIECES == 2 || PIECES == 4 || PIECES == 6 || PIECES == 8, "the staging waits name their registers");
     const u16 *xsrc[PIECES];
     bf16x8 *xdst[PIECES];
 #pragma unroll
@@ -196,6 +196,8 @@ __global__ __launch_bounds__(64 * WV) void wide_gemm_kernel(WideParams p) {
         for (int s = 0; s < WIDE_KS; ++s) gload_nt(wb[s], wsrc + (size_t)(cb * WIDE_KS + s) * 64);
         if constexpr (PIECES == 8)
             asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]), "+v"(xa[6]), "+v"(xa[7]) : "n"(X_WAIT));
+        else if constexpr (PIECES == 6)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xa[4]), "+v"(xa[5]) : "n"(X_WAIT));
         else if constexpr (PIECES == 4)
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]) : "n"(X_WAIT));
         else
@@ -229,6 +231,8 @@ __global__ __launch_bounds__(64 * WV) void wide_gemm_kernel(WideParams p) {
             // the other buffer was last read before the previous barrier
             if constexpr (PIECES == 8)
                 asm volatile("s_waitcnt vmcnt(%8)" : "+v"(xstage[0]), "+v"(xstage[1]), "+v"(xstage[2]), "+v"(xstage[3]), "+v"(xstage[4]), "+v"(xstage[5]), "+v"(xstage[6]), "+v"(xstage[7]) : "n"(X_WAIT));
+            else if constexpr (PIECES == 6)
+                asm volatile("s_waitcnt vmcnt(%6)" : "+v"(xstage[0]), "+v"(xstage[1]), "+v"(xstage[2]), "+v"(xstage[3]), "+v"(xstage[4]), "+v"(xstage[5]) : "n"(X_WAIT));
             else if constexpr (PIECES == 4)
                 asm volatile("s_waitcnt vmcnt(%4)" : "+v"(xstage[0]), "+v"(xstage[1]), "+v"(xstage[2]), "+v"(xstage[3]) : "n"(X_WAIT));
             else
@@ -380,11 +384,13 @@ void wide_launch(const WideParams &p, int m_pad, int n, hipStream_t st) {
         const dim3 grid((unsigned)(n / 128), (unsigned)p.splitk);
         if (m_pad == 32) hipLaunchKernelGGL((wide_gemm_kernel<1, 4, 8>), grid, dim3(256), 0, st, p);
         else if (m_pad == 64) hipLaunchKernelGGL((wide_gemm_kernel<2, 4, 8>), grid, dim3(256), 0, st, p);
+        else if (m_pad == 96) hipLaunchKernelGGL((wide_gemm_kernel<3, 4, 8>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((wide_gemm_kernel<4, 4, 8>), grid, dim3(256), 0, st, p);
     } else {
         const dim3 grid((unsigned)(n / 64), (unsigned)p.splitk);
         if (m_pad == 32) hipLaunchKernelGGL((wide_gemm_kernel<1, 2, 4>), grid, dim3(128), 0, st, p);
         else if (m_pad == 64) hipLaunchKernelGGL((wide_gemm_kernel<2, 2, 4>), grid, dim3(128), 0, st, p);
+        else if (m_pad == 96) hipLaunchKernelGGL((wide_gemm_kernel<3, 2, 4>), grid, dim3(128), 0, st, p);
         else hipLaunchKernelGGL((wide_gemm_kernel<4, 2, 4>), grid, dim3(128), 0, st, p);
     }
 }
@@ -401,7 +407,7 @@ int64_t crag_enc_wide_partial_bytes(int m_pad, int n, int splitk) {
 int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, int m_pad, int n, int k, int splitk,
                        void *stream) {
     if (!x || !ww || !partial) return wfail("wide_gemm: NULL pointer");
-    if (m_pad != 32 && m_pad != 64 && m_pad != 128) return wfail("wide_gemm: m_pad must be 32, 64 or 128 (got %d)", m_pad);
+    if (m_pad != 32 && m_pad != 64 && m_pad != 96 && m_pad != 128) return wfail("wide_gemm: m_pad must be 32, 64, 96 or 128 (got %d)", m_pad);
     if (n <= 0 || n % 128) return wfail("wide_gemm: n must be a multiple of 128 (got %d)", n);
     if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm: k must be a multiple of %d (got %d)", WIDE_BK, k);
     if (splitk <= 0 || splitk > k / WIDE_BK) return wfail("wide_gemm: splitk must be in [1, k / %d] (got %d)", WIDE_BK, splitk);
@@ -423,7 +429,7 @@ int crag_enc_wide_gemm(const uint16_t *x, const uint16_t *ww, float *partial, in
 int crag_enc_wide_gemm_rows(const uint16_t *x, const uint16_t *ww, float *partial, int m_pad, int n, int k, int splitk,
                             void *stream) {
     if (!x || !ww || !partial) return wfail("wide_gemm_rows: NULL pointer");
-    if (m_pad != 32 && m_pad != 64 && m_pad != 128) return wfail("wide_gemm_rows: m_pad must be 32, 64 or 128 (got %d)", m_pad);
+    if (m_pad != 32 && m_pad != 64 && m_pad != 96 && m_pad != 128) return wfail("wide_gemm_rows: m_pad must be 32, 64, 96 or 128 (got %d)", m_pad);
     if (n <= 0 || n % 128) return wfail("wide_gemm_rows: n must be a multiple of 128 (got %d)", n);
     if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm_rows: k must be a multiple of %d (got %d)", WIDE_BK, k);
     if (splitk <= 0 || splitk > k / WIDE_BK) return wfail("wide_gemm_rows: splitk must be in [1, k / %d] (got %d)", WIDE_BK, splitk);
@@ -465,7 +471,7 @@ int crag_enc_rmsnorm_partials(const float *partial_rows, int splitk, int m_pad, 
 int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *out, int m_rows, int m_pad, int n, int k,
                               int epilogue, void *stream) {
     if (!x || !ww || !out) return wfail("wide_gemm_direct: NULL pointer");
-    if (m_pad != 32 && m_pad != 64 && m_pad != 128) return wfail("wide_gemm_direct: m_pad must be 32, 64 or 128 (got %d)", m_pad);
+    if (m_pad != 32 && m_pad != 64 && m_pad != 96 && m_pad != 128) return wfail("wide_gemm_direct: m_pad must be 32, 64, 96 or 128 (got %d)", m_pad);
     if (m_rows <= 0 || m_rows > m_pad) return wfail("wide_gemm_direct: 0 < m_rows <= m_pad");
     if (n <= 0 || n % 128) return wfail("wide_gemm_direct: n must be a multiple of 128 (got %d)", n);
     if (k <= 0 || k % WIDE_BK) return wfail("wide_gemm_direct: k must be a multiple of %d (got %d)", WIDE_BK, k);
@@ -489,7 +495,7 @@ int crag_enc_wide_gemm_direct(const uint16_t *x, const uint16_t *ww, uint16_t *o
 int crag_enc_wide_reduce(const float *partial, uint16_t *out, int m_rows, int m_pad, int n, int splitk, int epilogue,
                          void *stream) {
     if (!partial || !out) return wfail("wide_reduce: NULL pointer");
-    if (m_pad != 32 && m_pad != 64 && m_pad != 128) return wfail("wide_reduce: m_pad must be 32, 64 or 128 (got %d)", m_pad);
+    if (m_pad != 32 && m_pad != 64 && m_pad != 96 && m_pad != 128) return wfail("wide_reduce: m_pad must be 32, 64, 96 or 128 (got %d)", m_pad);
     if (m_rows <= 0 || m_rows > m_pad) return wfail("wide_reduce: 0 < m_rows <= m_pad");
     if (n <= 0 || n % 128 || splitk <= 0) return wfail("wide_reduce: bad sizes n=%d splitk=%d", n, splitk);
     if (epilogue != 0 && epilogue != 1) return wfail("wide_reduce: epilogue must be 0 or 1");

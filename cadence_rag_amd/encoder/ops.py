@@ -207,7 +207,7 @@ _wide_scratch: dict = {}
 
 def wide_gemm(x: torch.Tensor, ww: torch.Tensor, out: torch.Tensor, m_rows: int, n: int, splitk: int,
               swiglu: bool = False, scratch: "torch.Tensor | None" = None):
-    """out[m_rows, n (or n/2)] = x[m_pad, k] @ W^T for m_pad = 32, 64 or 128 token rows: crag_enc_wide_gemm (split-K partial
+    """out[m_rows, n (or n/2)] = x[m_pad, k] @ W^T for m_pad = 32, 64, 96 or 128 token rows: crag_enc_wide_gemm (split-K partial
     tiles, fp32) + crag_enc_wide_reduce (sum of the splits, one rounding to bf16, optional SwiGLU).  scratch: fp32
     buffer of >= splitk * n * m_pad elements (one per device is kept otherwise: calls on one stream reuse it in order)."""
     _req(x, torch.bfloat16, "x"); _req(ww, torch.bfloat16, "ww"); _req(out, torch.bfloat16, "out")

@@ -364,12 +364,12 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
-        wide = self._wide_weights() if t in (64, 128) or wide32 else None
+        wide = self._wide_weights() if t in (64, 96, 128) or wide32 else None
         short_seqs = (0 < batch.max_len <= 32 and batch.n_seqs <= 65535 and skinny is None
                       and os.environ.get("CRAG_ENC_NO_SHORT_ATTN") is None)
         cs_tok = self._cos_sin.index_select(0, batch.positions.long()) if short_seqs else None   # once per forward
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
-        down_parts, down_split = None, (8 if t == 128 else 4)
+        down_parts, down_split = None, (8 if t >= 96 else 4)
         fuse_reduce = os.environ.get("CRAG_ENC_NO_FUSED_REDUCE") is None
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -535,18 +535,20 @@ class Qwen3Encoder:
     @torch.no_grad()
     def _forward_small(self, token_lists: Sequence[Sequence[int]], lens: Sequence[int], bucket: int) -> torch.Tensor:
         n = len(lens)
-        # 33..63 / 97..127 padded rows: phantom sequences round the batch up to 64 / 128 rows, where gate|up and down are
-        # the weight-streaming kernels (3 queries of 16 tokens: 3.66 ms through the library's GEMMs at 48 rows, 3.49 ms as
-        # 64 rows; 7 queries 4.48 -> 4.22 ms; at 80 / 96 rows the library's 4.0 ms beat the 128-row path's 4.24) -- their
-        # outputs are dropped below.  (32 rows stay 32 rows: the wide kernels take them as they are, forward_packed.)
+        # 33..127 padded rows that are not a multiple of 32: phantom sequences round the batch up to 64 / 96 / 128 rows,
+        # the heights the weight-streaming kernels are built for (3 queries of 16 tokens: 3.66 ms through the library's
+        # GEMMs at 48 rows, 3.16 ms as 64 rows; 5 queries 3.94 -> as 96 rows; 7 queries 4.48 -> 3.95 ms) -- their outputs
+        # are dropped below.  (32 / 64 / 96 / 128 rows go as they are, forward_packed.)
         n_real = n
-        if bucket <= 64 and (32 < n * bucket < 64 or 96 < n * bucket < 128) and self._wide_weights() is not None:
-            target = 64 if n * bucket < 64 else 128
+        if bucket <= 64 and (32 < n * bucket < 128) and n * bucket not in (64, 96) and self._wide_weights() is not None:
+            target = 64 if n * bucket < 64 else (96 if n * bucket < 96 else 128)
+            if target % bucket:          # (bucket 64: 96 rows do not divide)
+                target = 128
             if target % bucket == 0:
                 n = target // bucket
                 token_lists = list(token_lists) + [[0]] * (n - n_real)
                 lens = list(lens) + [1] * (n - n_real)
-        if n * bucket in (32, 64, 128):
+        if n * bucket in (32, 64, 96, 128):
             self._wide_weights()        # (a flip of CRAG_ENC_NO_WIDE drops the graphs captured over the other kernels)
         if n * bucket in (16, 32):
             self._skinny_weights()      # a flip of CRAG_ENC_SMALL_V1 / CRAG_ENC_NO_SKINNY drops the graphs captured over the other kernels

@@ -136,13 +136,13 @@ int crag_enc_small_attention_seqs_parts(const float *qkv_partial_rows, int split
                                         const int32_t *positions, const int32_t *cu_seqlens, int n_seqs, int max_len,
                                         uint16_t *out, int hq, int hkv, float eps, float scale, void *stream);
 
-/* ---- the linear layers at 32 / 64 / 128 token rows: what the gateway's batcher hands the model (RUNBOOK:304,331-334:
+/* ---- the linear layers at 32 / 64 / 96 / 128 token rows: what the gateway's batcher hands the model (RUNBOOK:304,331-334:
  * max_batch_size 8, preferred_batch_size [1, 2, 4, 8]) -- csrc/crag_encoder_wide.hip ----
  *
  * crag_enc_wide_gemm: partial[s] = X[m_pad, K_s] @ W[n, K_s]^T for the K ranges s = 0 .. splitk-1 (fp32), the weights
  * streamed once from HBM, the activations staged through LDS; 4 waves = 128 rows of W per workgroup, grid
  * (n / 128, splitk).
- *   x   [m_pad, k] bf16, m_pad = 32, 64 or 128 rows allocated and READ (padding rows must hold finite values)
+ *   x   [m_pad, k] bf16, m_pad = 32, 64, 96 or 128 rows allocated and READ (padding rows must hold finite values)
  *   ww  W in MFMA A-fragment order for v_mfma_f32_32x32x16_bf16: [n/32][k/16][lane = 32 (kk/8) + row][8]
  *       (torch: W.view(n/32, 32, k/16, 2, 8).permute(0, 2, 3, 1, 4).contiguous())
  *   partial  crag_enc_wide_partial_bytes(m_pad, n, splitk) bytes of scratch: the accumulators in register order

@@ -669,7 +669,7 @@ def test_small_attention_over_a_packed_batch_of_short_sequences(gpu, lens):
 
 @pytest.mark.parametrize("k,n,swiglu,splitk", [(2560, 6144, False, 4), (4096, 2560, False, 8), (9728, 2560, False, 8),
                                               (9728, 2560, False, 1), (2560, 19456, True, 1), (2560, 19456, True, 3)])
-@pytest.mark.parametrize("m_rows,m_pad", [(128, 128), (97, 128), (64, 64), (33, 64), (32, 32), (17, 32)])
+@pytest.mark.parametrize("m_rows,m_pad", [(128, 128), (97, 128), (96, 96), (70, 96), (64, 64), (33, 64), (32, 32), (17, 32)])
 def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, splitk, m_rows, m_pad):
     """crag_enc_wide_gemm + crag_enc_wide_reduce (the gateway's batch sizes, RUNBOOK:304,331-334: up to 8 short queries
     = 128 token rows) against torch: bf16 operands, fp32 accumulation over K splits added in split order, one rounding;
@@ -697,7 +697,8 @@ def test_wide_gemm_streams_the_weights_at_64_and_128_rows(gpu, k, n, swiglu, spl
         assert torch.allclose(got, want.float().cpu(), atol=3e-3, rtol=3e-2), (got - want.float().cpu()).abs().max()
 
 
-@pytest.mark.parametrize("m_rows,m_pad,splitk", [(32, 32, 4), (17, 32, 4), (64, 64, 4), (50, 64, 2), (128, 128, 8), (99, 128, 8)])
+@pytest.mark.parametrize("m_rows,m_pad,splitk", [(32, 32, 4), (17, 32, 4), (64, 64, 4), (50, 64, 2), (96, 96, 8), (80, 96, 4),
+                                                 (128, 128, 8), (99, 128, 8)])
 def test_split_k_partials_summed_by_the_norm_that_consumes_them(gpu, m_rows, m_pad, splitk):
     """crag_enc_wide_gemm_rows (the split-K partial tiles token-major) + crag_enc_rmsnorm_partials (sum of the splits,
     residual add, RMSNorm in ONE launch) against wide_gemm (partials + reduce launch) + rmsnorm: the same bits for the
@@ -728,7 +729,8 @@ def test_split_k_partials_summed_by_the_norm_that_consumes_them(gpu, m_rows, m_p
 
 @pytest.mark.parametrize("lens", [[16, 3, 9, 16, 1, 12, 7, 15], [16, 2, 11, 5], [40], [100], [30, 32, 17, 9],
                                   [16, 5, 9], [16, 3, 9, 16, 1, 12, 7],    # (these two: rounded up with phantom sequences)
-                                  [20], [32], [5, 16]])                      # (32 rows: the wide kernels at 32 rows)
+                                  [20], [32], [5, 16],                       # (32 rows: the wide kernels at 32 rows)
+                                  [16, 9, 16, 2, 11], [16] * 6, [70], [32, 20, 30]])   # (96 rows, the first after rounding up)
 def test_three_to_eight_short_queries_use_the_wide_projections_and_match_transformers(gpu, monkeypatch, lens):
     """The gateway's batch sizes (max_batch_size 8, preferred 1 / 2 / 4 / 8, RUNBOOK:304,331-334): 3 to 8 queries of
     <= 16 tokens, or one query of 33 to 128 tokens = one graph replay over 64 or 128 token rows, whose gate|up + SwiGLU
