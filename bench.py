@@ -591,6 +591,15 @@ def query_path_leg(enc, cfg, big_index, big, dev, dev_index, query_tokens: int =
                 "requests_per_s_pipelined": round(1.0 / r_rate, 1),
                 "queries_per_s_pipelined": round(nq / r_rate, 1),
             }
+        # encode latency alone over the shapes between one short query and the gateway's full batch (RUNBOOK:304,331-334):
+        # one query of 17..32 tokens, then 2 / 4 / 6 queries of `query_tokens` tokens (32 / 64 / 96 token rows)
+        sweep = {}
+        for nq, ntok in ((1, 2 * query_tokens), (2, query_tokens), (4, query_tokens), (6, query_tokens)):
+            tls = [rng.integers(0, cfg.vocab_size, size=ntok).tolist() for _ in range(nq)]
+            enc.embed_token_lists(tls)
+            ms = lat(lambda: enc.embed_token_lists(tls), 20) * 1e3
+            sweep[f"{nq}x{ntok}"] = {"encode_ms": round(ms, 4), "frac_of_weight_stream": round(weight_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        out["encode_latency_sweep"] = sweep
     finally:
         art.close()
     return out
@@ -659,6 +668,8 @@ def compact_line(full: dict) -> dict:
         "nq1_encode_ms": _get(full, "query_path", "nq1", "encode_ms"),
         "nq1_encode_frac": _get(full, "query_path", "nq1", "encode_roofline", "frac"),
         "nq1_request_ms": _get(full, "query_path", "nq1", "request_latency_ms"),
+        "q1x32_encode_ms": _get(full, "query_path", "encode_latency_sweep", "1x32", "encode_ms"),
+        "nq4_encode_ms": _get(full, "query_path", "encode_latency_sweep", "4x16", "encode_ms"),
         "nq8_encode_ms": _get(full, "query_path", "nq8", "encode_ms"),
         "nq8_encode_frac": _get(full, "query_path", "nq8", "encode_roofline", "frac"),
         "nq64_encode_ms": _get(full, "query_path", "nq64", "encode_ms"),
