@@ -860,6 +860,28 @@ def main() -> None:
                 "scan_kernel_us": round(leg["scan_us"], 1)}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
+        # the merged answer against the fp64 oracle (the checker, outside every timed region): every rank scores a sample of
+        # the queries against ITS shard on its host cores, rank 0 merges the per-shard oracle lists (score descending,
+        # id ascending -- the search's order) and compares them with what the exchange + merge left on the GPU
+        sharded_recall = None
+        if not args.no_cpu_baseline:
+            import oracle
+            oracle.set_threads(max(1, min(os.cpu_count() or 1, 64) // world))
+            sample = sorted({0, nq // 3, (2 * nq) // 3, nq - 1})
+            t_ids, t_sc, t_ct = oracle.exact_topk(queries.cpu().numpy()[sample], corpus.cpu().numpy(), k, mode=oracle.F64, fast=True)
+            mine_truth = [(t_sc[i, :t_ct[i]].tolist(), (t_ids[i, :t_ct[i]] + lo).tolist()) for i in range(len(sample))]
+            all_truth = [None] * world
+            dist.all_gather_object(all_truth, mine_truth)
+            if rank == 0:
+                got = f_ids.cpu().numpy()
+                hits = same = 0
+                for i, q in enumerate(sample):
+                    pairs = sorted(((-sc, rid) for r in all_truth for sc, rid in zip(*r[i])))[:k]
+                    want = [rid for _, rid in pairs]
+                    hits += len(set(want[:10]) & set(got[q, :10].tolist()))
+                    same += int(want == got[q, :len(want)].tolist())
+                sharded_recall = {"recall_at_10_vs_fp64_oracle": hits / float(len(sample) * min(k, 10)),
+                                  "topk_order_identical_to_oracle": same == len(sample), "queries_checked": len(sample)}
     if world > 1:  # max over ranks, per round
         t = torch.tensor(times, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -991,6 +1013,10 @@ def main() -> None:
         }
         if world > 1:
             line["config"]["per_rank_step_breakdown"] = per_rank
+            if sharded_recall is not None:   # (the sharded job's answer against the per-shard fp64 oracle lists, merged)
+                line["config"]["recall_at_10_vs_fp64_oracle"] = sharded_recall["recall_at_10_vs_fp64_oracle"]
+                line["config"]["topk_order_identical_to_oracle"] = sharded_recall["topk_order_identical_to_oracle"]
+                line["config"]["oracle_queries_checked"] = sharded_recall["queries_checked"]
             if same_job_1gpu is not None:
                 line["config"]["same_job_on_one_gpu"] = same_job_1gpu
                 if "value" in same_job_1gpu:

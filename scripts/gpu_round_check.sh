@@ -16,7 +16,7 @@ python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_steps20.json 2>> $O/bench.err
 # two ranks folded onto the one GPU of this box over gloo: the N > 1 code path (shards, exchange, merge, per-rank
 # breakdown) end to end; its times say nothing about xGMI
-CRAG_BENCH_BACKEND=gloo timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 100 --warmup 10 --rounds 2 --no-encode --no-cpu-baseline > $O/bench_n2_gloo_rehearsal.json 2> $O/bench_n2.err || true
+CRAG_BENCH_BACKEND=gloo timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 100 --warmup 10 --rounds 2 --no-encode > $O/bench_n2_gloo_rehearsal.json 2> $O/bench_n2.err || true
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
 # the headline leg alone (in the full command above the 1M legs launch the same kernel template)
