@@ -364,12 +364,18 @@ class Qwen3Encoder:
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
         last_only = c.pooling == "last" and os.environ.get("CRAG_ENC_FULL_LAST_LAYER") is None
+        full_last_wide = False   # (set below: the wide path keeps ALL rows in the last layer)
         wide = self._wide_weights() if t in (64, 96, 128) or wide32 else None
         short_seqs = (0 < batch.max_len <= 32 and batch.n_seqs <= 65535 and skinny is None
                       and os.environ.get("CRAG_ENC_NO_SHORT_ATTN") is None)
         cs_tok = self._cos_sin.index_select(0, batch.positions.long()) if short_seqs else None   # once per forward
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         down_parts, down_split = None, (8 if t >= 96 else 4)
+        if wide is not None and last_only and os.environ.get("CRAG_ENC_MIX_LAST_ONLY") is None:
+            # 32..128 rows through the weight-streaming kernels: the last layer's o / gate|up / down cost the same for
+            # 128 rows as for the 1..8 pooled ones (the weights are the stream), and the library's GEMMs at 1..8 rows
+            # stream them slower -- all rows stay in, the pooled rows are picked at the end
+            last_only, full_last_wide = False, True
         fuse_reduce = os.environ.get("CRAG_ENC_NO_FUSED_REDUCE") is None
         for i, L in enumerate(self.layers):
             if i == 0:
@@ -454,7 +460,11 @@ class Qwen3Encoder:
             else:
                 delta = F.linear(act, L["down"])
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
-        if c.pooling == "last":
+        if c.pooling == "last" and full_last_wide:
+            # the pooled rows are DATA (batch.last_tok: in a graph replay the real last token of every padded sequence)
+            ops.pool_normalize(resid.index_select(0, batch.last_tok), self.final_norm, batch.cu_one, out, c.out_dim, 0,
+                               c.rms_norm_eps, delta=delta.index_select(0, batch.last_tok))
+        elif c.pooling == "last":
             # residual + last delta and the final norm for the pooled rows only, inside the pool kernel
             ops.pool_normalize(resid, self.final_norm, batch.cu, out, c.out_dim, 0, c.rms_norm_eps, delta=delta)
         elif c.pooling == "mean":

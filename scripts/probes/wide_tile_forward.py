@@ -18,4 +18,4 @@ def lat(fn, n=40):
     return best
 for nq, ntok in ((1, 32), (4, 16), (8, 16)):
     toks = [rng.integers(0, cfg.vocab_size, size=ntok).tolist() for _ in range(nq)]
-    print(f"{nq} x {ntok} tokens [CRAG_WIDE_TILE={os.environ.get('CRAG_WIDE_TILE')}]: {lat(lambda: enc.embed_token_lists(toks)) * 1e3:.3f} ms", flush=True)
+    print(f"{nq} x {ntok} tokens [CRAG_WIDE_TILE={os.environ.get('CRAG_WIDE_TILE')} CRAG_ENC_MIX_LAST_ONLY={os.environ.get('CRAG_ENC_MIX_LAST_ONLY')}]: {lat(lambda: enc.embed_token_lists(toks)) * 1e3:.3f} ms", flush=True)
