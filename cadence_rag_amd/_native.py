@@ -71,6 +71,7 @@ SIGNATURES = {
     "crag_enc_qk_rope_vt": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int64, _c.c_int, _c.c_int, _c.c_float, _P, _P, _c.c_int64, _P]),
     "crag_enc_pool_normalize": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
     "crag_enc_pool_normalize_add": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
+    "crag_enc_pool_normalize_rows": (_c.c_int, [_P, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_float, _P]),
     "crag_enc_small_gemm": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_float, _P]),
     "crag_enc_wide_partial_bytes": (_c.c_int64, [_c.c_int, _c.c_int, _c.c_int]),

@@ -725,12 +725,15 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const u16 *gu, u16 *out, in
 // ---------------------------------------------------------------------------------------------
 // `delta` (nullable, mode 0): the last sub-block's output, added to the residual stream for the pooled rows only
 // (bf16 add, as the model's `hidden + mlp(...)`), instead of a pass over every token just to pool one per sequence.
+// `rows` (nullable, mode 0): the pooled row of sequence b is rows[b] instead of the sequence's last row (a graph replay
+// pools at the real last token of every padded sequence: data, not shape).
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const u16 *hs, const u16 *delta, const u16 *w, const int32_t *cu,
-                                                             float *out, int hidden, int out_dim, int mode, float eps) {
+                                                             const int64_t *rows, float *out, int hidden, int out_dim,
+                                                             int mode, float eps) {
     __shared__ float sh[4];
     __shared__ float row[8192];
     const int b = blockIdx.x;
-    const int t0 = cu[b], t1 = cu[b + 1];
+    const int t0 = rows ? (int)rows[b] : cu[b], t1 = rows ? t0 + 1 : cu[b + 1];
     if (t1 <= t0) {
         for (int i = threadIdx.x; i < out_dim; i += blockDim.x) out[(int64_t)b * out_dim + i] = 0.f;
         return;
@@ -983,8 +986,19 @@ int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *d
     if (hidden <= 0 || hidden > 8192 || out_dim <= 0 || out_dim > hidden) return efail("pool_normalize: bad sizes");
     if (n_seqs <= 0) return 0;
     hipLaunchKernelGGL(pool_normalize_kernel, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, hidden_states,
-                       delta, final_norm_w, cu_seqlens, out, hidden, out_dim, mode, eps);
+                       delta, final_norm_w, cu_seqlens, (const int64_t *)nullptr, out, hidden, out_dim, mode, eps);
     return hip_ok("pool_normalize");
+}
+
+int crag_enc_pool_normalize_rows(const uint16_t *hidden_states, const uint16_t *delta, const uint16_t *final_norm_w,
+                                 const int64_t *rows, float *out, int n_seqs, int hidden, int out_dim, float eps,
+                                 void *stream) {
+    if (!hidden_states || !final_norm_w || !rows || !out) return efail("pool_normalize_rows: NULL pointer");
+    if (hidden <= 0 || hidden > 8192 || out_dim <= 0 || out_dim > hidden) return efail("pool_normalize_rows: bad sizes");
+    if (n_seqs <= 0) return 0;
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3((unsigned)n_seqs), dim3(256), 0, (hipStream_t)stream, hidden_states,
+                       delta, final_norm_w, (const int32_t *)nullptr, rows, out, hidden, out_dim, 0, eps);
+    return hip_ok("pool_normalize_rows");
 }
 
 int crag_enc_skinny_gemm(const uint16_t *x, const uint16_t *wsw, uint16_t *out, int m_rows, int m_pad, int n, int k,

@@ -79,6 +79,20 @@ def pool_normalize(hidden_states, final_norm_w, cu, out, out_dim: int, mode: int
     return out
 
 
+def pool_normalize_rows(hidden_states, final_norm_w, rows, out, out_dim: int, eps: float, delta=None):
+    """Last-token pooling + final RMSNorm + slice + L2 normalise of the rows `rows` (int64 [B], device) of hidden_states
+    (+ delta): crag_enc_pool_normalize_rows -- the pooled rows are data, nothing is gathered first."""
+    _req(hidden_states, torch.bfloat16, "hidden_states"); _req(out, torch.float32, "out"); _req(rows, torch.int64, "rows")
+    if delta is not None:
+        _req(delta, torch.bfloat16, "delta")
+        if delta.shape != hidden_states.shape:
+            raise ValueError("delta must have the shape of hidden_states")
+    _native.check(_native.load().crag_enc_pool_normalize_rows(_p(hidden_states), _p(delta), _p(final_norm_w), _p(rows),
+                                                              _p(out), rows.numel(), hidden_states.shape[1], out_dim,
+                                                              float(eps), _stream()), "crag_enc_pool_normalize_rows")
+    return out
+
+
 def skinny_weight(weight: torch.Tensor) -> torch.Tensor:
     """[n, k] bf16 (torch Linear layout) -> the MFMA A-fragment order crag_enc_skinny_gemm streams
     ([n/16][k/32][lane = 16 (kk/8) + row][8]); n % 16 == 0, k % 32 == 0."""

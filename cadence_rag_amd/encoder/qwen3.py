@@ -83,6 +83,8 @@ class PackedBatch:
     last_tok: torch.Tensor    # int64 [B]: packed position of every sequence's last token
     cu_one: torch.Tensor      # int32 [B+1] = 0..B: the batch of last tokens as B one-token sequences
     max_len: int = 0          # longest sequence (host side: picks the attention kernel)
+    cs_tok: Optional[torch.Tensor] = None   # the RoPE table's rows of `positions`, [T, 64, 2] fp32: set by a caller that
+                                            # reuses the batch (the graph path: positions are a constant of the shape)
 
     @staticmethod
     def build(lengths: Sequence[int], device) -> "PackedBatch":
@@ -304,14 +306,17 @@ class Qwen3Encoder:
         t = batch.n_tokens
         width = c.q_size + 2 * c.kv_size
         res_a, res_b = x, torch.empty_like(x)
-        delta = torch.zeros(t, c.hidden_size, dtype=bf, device=dev)      # "no delta yet" in front of layer 0
+        zeros = self.__dict__.get("_zero_delta")                         # "no delta yet" in front of layer 0: a buffer
+        if zeros is None or zeros.shape[0] < t:                          # of zeros nobody writes, not a fill per forward
+            zeros = self._zero_delta = torch.zeros(32, c.hidden_size, dtype=bf, device=dev)
+        delta = zeros[:t]
         delta_o = torch.empty_like(delta)
         delta_d = torch.empty_like(delta)
         qkv = torch.empty(t, width, dtype=bf, device=dev)
         attn = torch.empty(t, c.q_size, dtype=bf, device=dev)
         act = torch.empty(t, c.intermediate_size, dtype=bf, device=dev)
         scale = 1.0 / math.sqrt(c.head_dim)
-        cs_tok = self._cos_sin.index_select(0, batch.positions.long())   # once per forward, not once per layer
+        cs_tok = batch.cs_tok if batch.cs_tok is not None else self._cos_sin.index_select(0, batch.positions.long())
         for i, L in enumerate(self.layers):
             W = skinny[i]
             ops.small_gemm(res_a, W["qkv"], qkv, t, width, 12, delta=delta if i == 0 else delta_d, norm_w=L["ln1"],
@@ -325,8 +330,7 @@ class Qwen3Encoder:
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
         if c.pooling == "last":
             # the pooled rows are DATA (batch.last_tok: in a graph replay the real last token of every padded sequence)
-            ops.pool_normalize(res_a.index_select(0, batch.last_tok), self.final_norm, batch.cu_one, out, c.out_dim, 0,
-                               c.rms_norm_eps, delta=delta_d.index_select(0, batch.last_tok))
+            ops.pool_normalize_rows(res_a, self.final_norm, batch.last_tok, out, c.out_dim, c.rms_norm_eps, delta=delta_d)
         else:
             normed = torch.empty_like(x)
             ops.rmsnorm(delta_d, self.final_norm, normed, c.rms_norm_eps, residual_in=res_a, residual_out=None)
@@ -368,7 +372,9 @@ class Qwen3Encoder:
         wide = self._wide_weights() if t in (64, 96, 128) or wide32 else None
         short_seqs = (0 < batch.max_len <= 32 and batch.n_seqs <= 65535 and skinny is None
                       and os.environ.get("CRAG_ENC_NO_SHORT_ATTN") is None)
-        cs_tok = self._cos_sin.index_select(0, batch.positions.long()) if short_seqs else None   # once per forward
+        cs_tok = None
+        if short_seqs:   # once per forward; in the graph path once per captured shape
+            cs_tok = batch.cs_tok if batch.cs_tok is not None else self._cos_sin.index_select(0, batch.positions.long())
         delta: Optional[torch.Tensor] = None  # output of the previous sub-block, added into the residual
         down_parts, down_split = None, (8 if t >= 96 else 4)
         if wide is not None and last_only and os.environ.get("CRAG_ENC_MIX_LAST_ONLY") is None:
@@ -462,8 +468,7 @@ class Qwen3Encoder:
         out = torch.empty(batch.n_seqs, c.out_dim, dtype=torch.float32, device=dev)
         if c.pooling == "last" and full_last_wide:
             # the pooled rows are DATA (batch.last_tok: in a graph replay the real last token of every padded sequence)
-            ops.pool_normalize(resid.index_select(0, batch.last_tok), self.final_norm, batch.cu_one, out, c.out_dim, 0,
-                               c.rms_norm_eps, delta=delta.index_select(0, batch.last_tok))
+            ops.pool_normalize_rows(resid, self.final_norm, batch.last_tok, out, c.out_dim, c.rms_norm_eps, delta=delta)
         elif c.pooling == "last":
             # residual + last delta and the final norm for the pooled rows only, inside the pool kernel
             ops.pool_normalize(resid, self.final_norm, batch.cu, out, c.out_dim, 0, c.rms_norm_eps, delta=delta)
@@ -519,6 +524,7 @@ class Qwen3Encoder:
         ids = d_in[:4 * t_rows].view(torch.int32)
         batch.last_tok = d_in[off_last:].view(torch.int64)
         batch.last_tok.copy_(torch.arange(1, n_seqs + 1, dtype=torch.int64, device=self.device) * bucket - 1)
+        batch.cs_tok = self._cos_sin.index_select(0, batch.positions.long())   # outside the graph: a constant of the shape
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):          # warm-up outside the capture (library handles, autotuning)

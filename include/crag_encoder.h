@@ -74,6 +74,12 @@ int crag_enc_pool_normalize(const uint16_t *hidden_states, const uint16_t *final
 int crag_enc_pool_normalize_add(const uint16_t *hidden_states, const uint16_t *delta, const uint16_t *final_norm_w,
                                 const int32_t *cu_seqlens, float *out, int n_seqs, int hidden, int out_dim,
                                 int mode, float eps, void *stream);
+/* Last-token pooling with the pooled rows given as DATA: sequence b pools row rows[b] of hidden_states (+ delta, nullable)
+ * -- what a graph replay over padded sequences needs (the real last token of every sequence) without gathering the rows
+ * first. */
+int crag_enc_pool_normalize_rows(const uint16_t *hidden_states, const uint16_t *delta, const uint16_t *final_norm_w,
+                                 const int64_t *rows, float *out, int n_seqs, int hidden, int out_dim, float eps,
+                                 void *stream);
 
 /* Linear layer for m_rows <= 32 tokens -- ONE query per /retrieve request (retrieve.py:427) -- as a weight stream:
  * out[m_rows, n] = x[m_rows, k] @ W[n, k]^T (bf16 in, fp32 accumulate, bf16 out).

@@ -241,6 +241,25 @@ def _hf_embed(model, cfg, token_lists, pooling):
     return torch.stack(outs)
 
 
+def test_pool_normalize_of_rows_given_as_data_equals_gather_then_pool(gpu):
+    """crag_enc_pool_normalize_rows (the pooled rows as an int64 device array: what a graph replay over padded sequences
+    needs) against index_select + crag_enc_pool_normalize_add over one-row sequences: the same bits."""
+    from cadence_rag_amd.encoder import ops
+    g = torch.Generator().manual_seed(77)
+    t, hidden, out_dim = 40, 2560, 1024
+    hs, delta = _bf(torch.randn(t, hidden, generator=g)), _bf(torch.randn(t, hidden, generator=g) * 0.1)
+    w = _bf(1 + 0.1 * torch.randn(hidden, generator=g))
+    rows = torch.tensor([39, 0, 17, 17, 5], dtype=torch.int64, device=DEV)
+    cu_one = torch.arange(rows.numel() + 1, dtype=torch.int32, device=DEV)
+    for d in (delta, None):
+        want = torch.empty(rows.numel(), out_dim, dtype=torch.float32, device=DEV)
+        ops.pool_normalize(hs.index_select(0, rows), w, cu_one, want, out_dim, 0, 1e-6,
+                           delta=None if d is None else d.index_select(0, rows))
+        got = torch.full((rows.numel() + 1, out_dim), 3.0, dtype=torch.float32, device=DEV)
+        ops.pool_normalize_rows(hs, w, rows, got[:rows.numel()], out_dim, 1e-6, delta=d)
+        assert torch.equal(got[:rows.numel()], want) and torch.all(got[rows.numel()] == 3.0)
+
+
 @pytest.mark.parametrize("pooling", ["last", "mean"])
 def test_full_forward_matches_transformers_qwen3(gpu, pooling):
     model, enc, cfg = _tiny_hf_and_mine(pooling)
