@@ -47,9 +47,13 @@ _encoder: Optional[Encoder] = None
 _encoder_lock = threading.Lock()  # FastAPI runs sync endpoints on a threadpool: one GPU submission at a time
 
 
-def set_encoder(encoder: Optional[Encoder]) -> None:
+def set_encoder(encoder: Optional[Encoder], warm: bool = True) -> None:
+    """Register the in-process encoder.  warm: let it build what its short-query paths want NOW (Qwen3Encoder.warm_up:
+    the re-tiled weight copies, seconds of work) instead of inside the first /retrieve request."""
     global _encoder
     _encoder = encoder
+    if warm and encoder is not None and callable(getattr(encoder, "warm_up", None)):
+        encoder.warm_up()
 
 
 def get_encoder() -> Optional[Encoder]:
